@@ -1,0 +1,260 @@
+"""ctypes binding of the MI355X CoMD hot path (libcomd_host.so + libcomd_hip.so).
+
+This is plumbing for tests and bench.py: every call goes through the C ABI declared in
+include/comd_hip.h and comd-cuda-async_amd/csrc/host/comd_host.h.  There is no Python or CPU
+fallback: if the HIP library is missing, loading fails with an ImportError that says how to build it.
+
+The directory name contains '-', so import it with `__graft_entry__.load_package()`.
+"""
+import ctypes
+import os
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_CSRC = os.path.join(_HERE, "csrc")
+REPO_ROOT = os.path.dirname(_HERE)
+POT_DIR = os.path.join(REPO_ROOT, "pots")
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int_p = ctypes.POINTER(ctypes.c_int)
+
+
+class HostAtoms(ctypes.Structure):
+    """include/comd_hip.h HostAtoms"""
+    _fields_ = [("nAtoms", c_int_p), ("gid", c_int_p), ("iSpecies", c_int_p)] + \
+               [(n, c_double_p) for n in ("rx", "ry", "rz", "px", "py", "pz", "fx", "fy", "fz", "e")]
+
+
+SENDRECV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
+                               ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+BCAST_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
+BARRIER_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+
+
+class CommTransport(ctypes.Structure):
+    """include/comd_hip.h CommTransport"""
+    _fields_ = [("ctx", ctypes.c_void_p), ("sendrecv", SENDRECV_FN), ("allreduce", ALLREDUCE_FN),
+                ("bcast", BCAST_FN), ("barrier", BARRIER_FN)]
+
+
+_libs = {}
+
+
+def _load(name):
+    if name in _libs:
+        return _libs[name]
+    path = os.path.join(_CSRC, name)
+    if not os.path.exists(path):
+        raise ImportError(f"{path} is missing: build it with `make -C {_CSRC}` (hipcc --offload-arch=gfx950). "
+                          "There is no CPU fallback for the product path.")
+    _libs[name] = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+    return _libs[name]
+
+
+def lib_hip():
+    """libcomd_hip.so: HIP kernels + C-ABI launch wrappers."""
+    lib = _load("libcomd_hip.so")
+    if not getattr(lib, "_typed", False):
+        lib.SetupGpu.argtypes = [ctypes.c_int] * 3
+        lib.SetupGpu.restype = ctypes.c_int
+        lib.comdDeviceCount.restype = ctypes.c_int
+        lib.comdCommGetUniqueId.argtypes = [ctypes.c_char_p]
+        lib.comdCommInitRank.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(CommTransport)]
+        lib.comdForceTimingEnable.argtypes = [ctypes.c_int]
+        lib.comdForceTimingTotalMs.argtypes = [c_int_p]
+        lib.comdForceTimingTotalMs.restype = ctypes.c_double
+        lib.comdEventCreate.restype = ctypes.c_void_p
+        lib.comdEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.comdEventElapsedMs.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.comdEventElapsedMs.restype = ctypes.c_float
+        lib.comdEventDestroy.argtypes = [ctypes.c_void_p]
+        lib._typed = True
+    return lib
+
+
+def lib_host():
+    """libcomd_host.so: the C host (CLI, decomposition, link cells, potentials, halo exchange, time step)."""
+    lib_hip()
+    lib = _load("libcomd_host.so")
+    if not getattr(lib, "_typed", False):
+        vp = ctypes.c_void_p
+        lib.comdCreate.restype = vp
+        lib.comdCreate.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+        lib.comdCreateHostOnly.restype = vp
+        lib.comdCreateHostOnly.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+        lib.comdMain.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
+        lib.comdDestroy.argtypes = [vp]
+        lib.comdGetEnergy.argtypes = [vp, c_double_p]
+        lib.comdNumGlobal.argtypes = [vp]
+        lib.comdNumLocalSlots.argtypes = [vp]
+        lib.comdFetchAtoms.argtypes = [vp]
+        lib.comdFetchAtoms.restype = ctypes.POINTER(HostAtoms)
+        lib.comdHostAtoms.argtypes = [vp]
+        lib.comdHostAtoms.restype = ctypes.POINTER(HostAtoms)
+        lib.comdGridInfo.argtypes = [vp, c_int_p]
+        lib.comdSimBoxFromTuple.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        lib.comdSimBoxFromCoord.argtypes = [vp, c_double_p]
+        lib.comdFaceCells.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        lib.comdNeighborRanks.argtypes = [vp, c_int_p, c_int_p]
+        lib.comdGatherByGid.argtypes = [vp, ctypes.c_int, c_double_p]
+        lib.comdScatterByGid.argtypes = [vp, ctypes.c_int, c_double_p]
+        lib.timestep.argtypes = [vp, ctypes.c_int, ctypes.c_double]
+        lib.timestep.restype = ctypes.c_double
+        for fn in ("redistributeAtoms", "computeForce", "kineticEnergyGpu", "sumAtoms"):
+            getattr(lib, fn).argtypes = [vp]
+        lib.initParallel.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.POINTER(CommTransport)]
+        lib.getMyRank.restype = ctypes.c_int
+        lib.getNRanks.restype = ctypes.c_int
+        lib._typed = True
+    return lib
+
+
+def _argv(args):
+    argv = [b"comd"] + [str(a).encode() for a in args]
+    arr = (ctypes.c_char_p * (len(argv) + 1))(*argv, None)
+    return len(argv), arr
+
+
+def setup_gpu(device=0, rank=0, verbose=False):
+    """SetupGpu (gpu_utility.c:32-71).  Raises if no HIP device is visible."""
+    hip = lib_hip()
+    if hip.comdDeviceCount() < 1:
+        raise RuntimeError("no HIP device visible: the product path has no CPU fallback")
+    return hip.SetupGpu(device, rank, 1 if verbose else 0)
+
+
+def init_parallel(rank=0, n_ranks=1, transport=None):
+    lib_host().initParallel(rank, n_ranks, ctypes.byref(transport) if transport is not None else None)
+
+
+def rccl_transport(rank, n_ranks, unique_id):
+    """Join the RCCL communicator (after setup_gpu) and return the transport to hand to init_parallel."""
+    t = CommTransport()
+    rc = lib_hip().comdCommInitRank(unique_id, rank, n_ranks, ctypes.byref(t))
+    if rc != 0:
+        raise RuntimeError("comdCommInitRank failed")
+    return t
+
+
+def rccl_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    if lib_hip().comdCommGetUniqueId(buf) != 0:
+        raise RuntimeError("comdCommGetUniqueId failed")
+    return buf.raw
+
+
+class Simulation:
+    """One rank's SimFlat (CoMDTypes.h:75-135) driven through the C ABI.
+
+    args are the reference's CoMD command-line flags, e.g. ["-x", 20, "-y", 20, "-z", 20, "-m", "thread_atom"].
+    """
+
+    def __init__(self, args, host_only=False):
+        import numpy as np
+        self._np = np
+        self.lib = lib_host()
+        args = list(args)
+        if "-d" not in args and "--potDir" not in args:
+            args += ["-d", POT_DIR]
+        if "--quiet" not in args:
+            args += ["--quiet"]
+        argc, argv = _argv(args)
+        self.host_only = host_only
+        self.ptr = (self.lib.comdCreateHostOnly if host_only else self.lib.comdCreate)(argc, argv)
+        if not self.ptr:
+            raise RuntimeError("simulation creation failed")
+        info = (ctypes.c_int * 6)()
+        self.lib.comdGridInfo(self.ptr, info)
+        self.grid = tuple(info[0:3])
+        self.n_local_boxes, self.n_total_boxes, self.max_atoms = info[3], info[4], info[5]
+
+    # --- time stepping (timestep.c) ---
+    def step(self, n, dt=1.0):
+        return self.lib.timestep(self.ptr, n, dt)
+
+    def redistribute(self):
+        self.lib.redistributeAtoms(self.ptr)
+
+    def compute_force(self):
+        self.lib.computeForce(self.ptr)
+
+    def kinetic_energy(self):
+        self.lib.kineticEnergyGpu(self.ptr)
+
+    def sum_atoms(self):
+        self.lib.sumAtoms(self.ptr)
+
+    # --- results ---
+    def energy(self):
+        """(ePotential, eKinetic, nGlobal) totals in eV."""
+        out = (ctypes.c_double * 3)()
+        self.lib.comdGetEnergy(self.ptr, out)
+        return out[0], out[1], int(out[2])
+
+    @property
+    def n_global(self):
+        return self.lib.comdNumGlobal(self.ptr)
+
+    def gather(self, which, out=None):
+        """Per-atom array of this rank's local atoms keyed by gid: 0 r, 1 p, 2 f -> (n,3); 3 e, 4 rhobar, 5 dfEmbed -> (n,)."""
+        np = self._np
+        n = self.n_global
+        if out is None:
+            out = np.zeros((n, 3) if which < 3 else (n,), dtype=np.float64)
+        self.lib.comdGatherByGid(self.ptr, which, out.ctypes.data_as(c_double_p))
+        return out
+
+    def scatter(self, which, arr):
+        np = self._np
+        arr = np.ascontiguousarray(arr, dtype=np.float64)
+        self.lib.comdScatterByGid(self.ptr, which, arr.ctypes.data_as(c_double_p))
+
+    def cells(self):
+        """Slot arrays (device state copied to the host mirror; host mirror only when host_only):
+        dict of nAtoms [nTotalBoxes], gid [nTotalBoxes, maxAtoms] and r/p/f components."""
+        np = self._np
+        h = (self.lib.comdHostAtoms if self.host_only else self.lib.comdFetchAtoms)(self.ptr).contents
+        nb, cap = self.n_total_boxes, self.max_atoms
+        out = {"nAtoms": np.ctypeslib.as_array(h.nAtoms, shape=(nb,)).copy(),
+               "gid": np.ctypeslib.as_array(h.gid, shape=(nb, cap)).copy()}
+        for k in ("rx", "ry", "rz", "px", "py", "pz", "fx", "fy", "fz", "e"):
+            out[k] = np.ctypeslib.as_array(getattr(h, k), shape=(nb, cap)).copy()
+        return out
+
+    def box_from_tuple(self, ix, iy, iz):
+        return self.lib.comdSimBoxFromTuple(self.ptr, ix, iy, iz)
+
+    def box_from_coord(self, r):
+        v = (ctypes.c_double * 3)(*r)
+        return self.lib.comdSimBoxFromCoord(self.ptr, v)
+
+    def face_cells(self, kind, face):
+        np = self._np
+        n = self.lib.comdFaceCells(self.ptr, kind, face, None)
+        a = np.zeros(n, dtype=np.int32)
+        self.lib.comdFaceCells(self.ptr, kind, face, a.ctypes.data)
+        return a
+
+    def neighbor_ranks(self):
+        nbr = (ctypes.c_int * 6)()
+        coord = (ctypes.c_int * 3)()
+        self.lib.comdNeighborRanks(self.ptr, nbr, coord)
+        return list(nbr), list(coord)
+
+    def close(self):
+        if self.ptr:
+            self.lib.comdDestroy(self.ptr)
+            self.ptr = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+def run_main(args):
+    """The reference's main() (CoMD.c:86-187): full stdout report + YAML file."""
+    argc, argv = _argv(list(args))
+    return lib_host().comdMain(argc, argv)

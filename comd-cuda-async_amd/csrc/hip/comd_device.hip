@@ -1,0 +1,517 @@
+// comd_device.hip -- launch wrappers and device-memory management behind include/comd_hip.h.
+//
+// Stands where the reference's gpu_kernels.cu (extern "C" wrappers, :69-660, :1013-1059) and the device half of
+// gpu_utility.c (:32-347, :432-653) do.  gfx950 only; built with hipcc --offload-arch=gfx950.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "comd_hip.h"
+#include "device_common.h"
+#include "lj_kernels.h"
+#include "eam_kernels.h"
+#include "step_kernels.h"
+
+static int g_rank = 0;
+
+#define HIP_CHECK(cmd)                                                                                     \
+   do {                                                                                                    \
+      hipError_t status_ = (cmd);                                                                          \
+      if (status_ != hipSuccess) {                                                                         \
+         int dev_ = -1; (void)hipGetDevice(&dev_);                                                         \
+         fprintf(stderr, "Rank %d, GPU: %d, Error in file %s at line %d\n", g_rank, dev_, __FILE__, __LINE__); \
+         fprintf(stderr, "HIP error %d: %s\n", (int)status_, hipGetErrorString(status_));                  \
+         exit(-1);                                                                                         \
+      }                                                                                                    \
+   } while (0)
+
+#define LAUNCH_CHECK() HIP_CHECK(hipGetLastError())
+
+static inline hipStream_t S(comdStream_t s) { return (hipStream_t)s; }
+static inline int ceilDiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- force-kernel timing (bench.py roofline leg) ---------------------------------------------------------
+static bool g_timing = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_evPool;
+static size_t g_evUsed = 0;
+static double g_forceMs = 0.0;
+static int g_forceLaunches = 0;
+
+static void timingFlush()
+{
+   for (size_t i = 0; i < g_evUsed; ++i) {
+      float ms = 0.f;
+      HIP_CHECK(hipEventSynchronize(g_evPool[i].second));
+      HIP_CHECK(hipEventElapsedTime(&ms, g_evPool[i].first, g_evPool[i].second));
+      g_forceMs += ms;
+   }
+   g_forceLaunches += (int)g_evUsed;
+   g_evUsed = 0;
+}
+
+struct ForceTimer {
+   hipStream_t st; int idx;
+   explicit ForceTimer(hipStream_t s) : st(s), idx(-1)
+   {
+      if (!g_timing) return;
+      if (g_evUsed == g_evPool.size()) {
+         if (g_evPool.size() >= 1024) timingFlush();
+         else { hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); g_evPool.push_back({a, b}); }
+      }
+      idx = (int)g_evUsed++;
+      HIP_CHECK(hipEventRecord(g_evPool[idx].first, st));
+   }
+   ~ForceTimer() { if (idx >= 0) HIP_CHECK(hipEventRecord(g_evPool[idx].second, st)); }
+};
+
+extern "C" void comdForceTimingEnable(int on) { g_timing = on != 0; }
+extern "C" void comdForceTimingReset(void) { timingFlush(); g_forceMs = 0.0; g_forceLaunches = 0; }
+extern "C" double comdForceTimingTotalMs(int* nLaunches) { timingFlush(); if (nLaunches) *nLaunches = g_forceLaunches; return g_forceMs; }
+
+extern "C" void* comdEventCreate(void) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return (void*)e; }
+extern "C" void comdEventRecord(void* ev, comdStream_t stream) { HIP_CHECK(hipEventRecord((hipEvent_t)ev, S(stream))); }
+extern "C" float comdEventElapsedMs(void* start, void* stop)
+{
+   float ms = 0.f;
+   HIP_CHECK(hipEventSynchronize((hipEvent_t)stop));
+   HIP_CHECK(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+   return ms;
+}
+extern "C" void comdEventDestroy(void* ev) { HIP_CHECK(hipEventDestroy((hipEvent_t)ev)); }
+
+// ---- device management ---------------------------------------------------------------------------------------
+extern "C" int comdDeviceCount(void)
+{
+   int n = 0;
+   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+   return n;
+}
+
+extern "C" int SetupGpu(int deviceId, int rank, int verbose)
+{
+   g_rank = rank;
+   HIP_CHECK(hipSetDevice(deviceId));
+   hipDeviceProp_t props;
+   HIP_CHECK(hipGetDeviceProperties(&props, deviceId));
+   if (verbose)
+      printf("Rank %d: device %d = %s (%s), %d CUs, %.1f GiB\n", rank, deviceId, props.name, props.gcnArchName,
+             props.multiProcessorCount, props.totalGlobalMem / 1073741824.0);
+   return props.multiProcessorCount;
+}
+
+extern "C" void comdDeviceSynchronize(void) { HIP_CHECK(hipDeviceSynchronize()); }
+extern "C" void comdStreamSynchronize(comdStream_t stream) { HIP_CHECK(hipStreamSynchronize(S(stream))); }
+extern "C" void* comdDeviceMalloc(long bytes) { void* p = nullptr; HIP_CHECK(hipMalloc(&p, (size_t)(bytes > 0 ? bytes : 8))); return p; }
+extern "C" void comdDeviceFree(void* p) { if (p) HIP_CHECK(hipFree(p)); }
+extern "C" void* comdHostMallocPinned(long bytes) { void* p = nullptr; HIP_CHECK(hipHostMalloc(&p, (size_t)(bytes > 0 ? bytes : 8), hipHostMallocDefault)); return p; }
+extern "C" void comdHostFreePinned(void* p) { if (p) HIP_CHECK(hipHostFree(p)); }
+extern "C" void comdMemcpyHtoD(void* dst, const void* src, long bytes) { HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice)); }
+extern "C" void comdMemcpyDtoH(void* dst, const void* src, long bytes) { HIP_CHECK(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost)); }
+extern "C" void comdMemcpyDtoDAsync(void* dst, const void* src, long bytes, comdStream_t stream)
+{
+   HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, S(stream)));
+}
+
+template <typename T> static T* dalloc(size_t n, bool zero = true)
+{
+   T* p = nullptr;
+   HIP_CHECK(hipMalloc((void**)&p, (n ? n : 1) * sizeof(T)));
+   if (zero) HIP_CHECK(hipMemset(p, 0, (n ? n : 1) * sizeof(T)));
+   return p;
+}
+
+static void uploadTable(InterpolationObjectGpu* t, int n, real_t x0, real_t invDx, const real_t* hostValues)
+{
+   t->n = n; t->x0 = x0; t->invDx = invDx;
+   t->xn = x0 + n / invDx;                     // gpu_utility.c:446, 460-461
+   t->invDxHalf = invDx * 0.5;
+   t->invDxXx0 = x0 * invDx;
+   t->values = dalloc<real_t>((size_t)n + 3, false);
+   HIP_CHECK(hipMemcpy(t->values, hostValues, ((size_t)n + 3) * sizeof(real_t), hipMemcpyHostToDevice));
+}
+
+extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
+{
+   memset(sim, 0, sizeof(*sim));
+   HIP_CHECK(hipGetDevice(&sim->deviceId));
+   sim->rank = cfg->rank; g_rank = cfg->rank;
+   sim->maxAtoms = cfg->maxAtoms;
+   sim->do_eam = cfg->do_eam;
+   sim->mass = cfg->mass;
+   if (cfg->maxAtoms < 1 || cfg->maxAtoms > 1024) { fprintf(stderr, "AllocateGpu: maxAtoms %d outside [1,1024]\n", cfg->maxAtoms); exit(-1); }
+   if (!cfg->do_eam && (cfg->maxAtoms % 64) != 0) { fprintf(stderr, "AllocateGpu: LJ needs maxAtoms %% 64 == 0 (got %d)\n", cfg->maxAtoms); exit(-1); }
+
+   LinkCellGpu* b = &sim->boxes;
+   b->nLocalBoxes = cfg->nLocalBoxes; b->nTotalBoxes = cfg->nTotalBoxes;
+   for (int a = 0; a < 3; ++a) {
+      b->gridSize[a] = cfg->gridSize[a]; b->localMin[a] = cfg->localMin[a]; b->localMax[a] = cfg->localMax[a];
+      b->invBoxSize[a] = 1.0 / cfg->boxSize[a];
+   }
+   const size_t slots = (size_t)cfg->nTotalBoxes * cfg->maxAtoms;      // 64-bit: 256^3 LJ needs 136 M slots
+   b->nAtoms = dalloc<int>(cfg->nTotalBoxes);
+   AtomsGpu* at = &sim->atoms;
+   at->r.x = dalloc<real_t>(slots); at->r.y = dalloc<real_t>(slots); at->r.z = dalloc<real_t>(slots);
+   at->p.x = dalloc<real_t>(slots); at->p.y = dalloc<real_t>(slots); at->p.z = dalloc<real_t>(slots);
+   at->f.x = dalloc<real_t>(slots); at->f.y = dalloc<real_t>(slots); at->f.z = dalloc<real_t>(slots);
+   at->e = dalloc<real_t>(slots);
+   at->iSpecies = dalloc<int>(slots); at->gid = dalloc<int>(slots);
+   sim->neighbor_cells = dalloc<int>((size_t)cfg->nLocalBoxes * 27, false);
+   HIP_CHECK(hipMemcpy(sim->neighbor_cells, cfg->neighborCells, (size_t)cfg->nLocalBoxes * 27 * sizeof(int), hipMemcpyHostToDevice));
+   sim->species_mass = dalloc<real_t>(1, false);
+   HIP_CHECK(hipMemcpy(sim->species_mass, &cfg->mass, sizeof(real_t), hipMemcpyHostToDevice));
+
+   sim->lj_pot.cutoff = cfg->ljCutoff; sim->lj_pot.sigma = cfg->ljSigma; sim->lj_pot.epsilon = cfg->ljEpsilon;
+   if (cfg->do_eam) {
+      sim->eam_pot.cutoff = cfg->eamCutoff;
+      uploadTable(&sim->eam_pot.phi, cfg->nPhi, cfg->phiX0, cfg->phiInvDx, cfg->phiValues);
+      uploadTable(&sim->eam_pot.rho, cfg->nRho, cfg->rhoX0, cfg->rhoInvDx, cfg->rhoValues);
+      uploadTable(&sim->eam_pot.f,   cfg->nF,   cfg->fX0,   cfg->fInvDx,   cfg->fValues);
+      sim->eam_pot.rhobar = dalloc<real_t>(slots);
+      sim->eam_pot.dfEmbed = dalloc<real_t>(slots);
+   }
+   sim->nAtomsPrev = dalloc<int>(cfg->nTotalBoxes);
+   sim->cellDirty = dalloc<int>(cfg->nTotalBoxes);
+   sim->status = dalloc<int>(4);
+   sim->reduceBlocks = 1024;
+   sim->reduceBuf = dalloc<real_t>(2 * (size_t)sim->reduceBlocks + 2);
+   HIP_CHECK(hipHostMalloc((void**)&sim->pinned, 64 * sizeof(real_t), hipHostMallocDefault));
+
+   if (cfg->gpuAsync) {                         // gpu_utility.c:150-159
+      hipStream_t bs, is;
+      int lo = 0, hi = 0;
+      HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+      HIP_CHECK(hipStreamCreateWithPriority(&bs, hipStreamNonBlocking, hi));
+      HIP_CHECK(hipStreamCreateWithFlags(&is, hipStreamNonBlocking));
+      sim->boundary_stream = (comdStream_t)bs; sim->interior_stream = (comdStream_t)is;
+   } else {
+      sim->boundary_stream = nullptr; sim->interior_stream = nullptr;
+   }
+}
+
+extern "C" void SetBoundaryCells(SimGpu* sim, int nBoundary, const int* boundary, int nInterior, const int* interior,
+                                 int nBoundary1, const int* boundary1)
+{
+   sim->n_boundary_cells = nBoundary; sim->n_interior_cells = nInterior; sim->n_boundary1_cells = nBoundary1;
+   sim->boundary_cells = dalloc<int>(nBoundary, false);
+   sim->interior_cells = dalloc<int>(nInterior, false);
+   sim->boundary1_cells = dalloc<int>(nBoundary1, false);
+   if (nBoundary)  HIP_CHECK(hipMemcpy(sim->boundary_cells, boundary, (size_t)nBoundary * sizeof(int), hipMemcpyHostToDevice));
+   if (nInterior)  HIP_CHECK(hipMemcpy(sim->interior_cells, interior, (size_t)nInterior * sizeof(int), hipMemcpyHostToDevice));
+   if (nBoundary1) HIP_CHECK(hipMemcpy(sim->boundary1_cells, boundary1, (size_t)nBoundary1 * sizeof(int), hipMemcpyHostToDevice));
+}
+
+extern "C" void CopyDataToGpu(SimGpu* sim, const HostAtoms* h)
+{
+   const size_t slots = (size_t)sim->boxes.nTotalBoxes * sim->maxAtoms;
+   HIP_CHECK(hipMemcpy(sim->boxes.nAtoms, h->nAtoms, (size_t)sim->boxes.nTotalBoxes * sizeof(int), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.gid, h->gid, slots * sizeof(int), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.iSpecies, h->iSpecies, slots * sizeof(int), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.r.x, h->rx, slots * sizeof(real_t), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.r.y, h->ry, slots * sizeof(real_t), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.r.z, h->rz, slots * sizeof(real_t), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.p.x, h->px, slots * sizeof(real_t), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.p.y, h->py, slots * sizeof(real_t), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.p.z, h->pz, slots * sizeof(real_t), hipMemcpyHostToDevice));
+}
+
+extern "C" void GetDataFromGpu(SimGpu* sim, HostAtoms* h)
+{
+   HIP_CHECK(hipDeviceSynchronize());
+   const size_t slots = (size_t)sim->boxes.nTotalBoxes * sim->maxAtoms;
+   HIP_CHECK(hipMemcpy(h->nAtoms, sim->boxes.nAtoms, (size_t)sim->boxes.nTotalBoxes * sizeof(int), hipMemcpyDeviceToHost));
+   HIP_CHECK(hipMemcpy(h->gid, sim->atoms.gid, slots * sizeof(int), hipMemcpyDeviceToHost));
+   HIP_CHECK(hipMemcpy(h->iSpecies, sim->atoms.iSpecies, slots * sizeof(int), hipMemcpyDeviceToHost));
+   real_t* dst[10] = { h->rx, h->ry, h->rz, h->px, h->py, h->pz, h->fx, h->fy, h->fz, h->e };
+   real_t* src[10] = { sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
+                       sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.e };
+   for (int i = 0; i < 10; ++i) if (dst[i]) HIP_CHECK(hipMemcpy(dst[i], src[i], slots * sizeof(real_t), hipMemcpyDeviceToHost));
+}
+
+extern "C" void updateNAtomsCpu(SimGpu* sim, int* nAtomsHost)
+{
+   HIP_CHECK(hipDeviceSynchronize());
+   HIP_CHECK(hipMemcpy(nAtomsHost, sim->boxes.nAtoms, (size_t)sim->boxes.nTotalBoxes * sizeof(int), hipMemcpyDeviceToHost));
+}
+
+extern "C" void DestroyGpu(SimGpu* sim)
+{
+   HIP_CHECK(hipDeviceSynchronize());
+   timingFlush();
+   void* ptrs[] = { sim->boxes.nAtoms, sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
+                    sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.e, sim->atoms.iSpecies, sim->atoms.gid,
+                    sim->neighbor_cells, sim->species_mass, sim->eam_pot.phi.values, sim->eam_pot.rho.values, sim->eam_pot.f.values,
+                    sim->eam_pot.rhobar, sim->eam_pot.dfEmbed, sim->nAtomsPrev, sim->cellDirty, sim->status, sim->reduceBuf,
+                    sim->boundary_cells, sim->interior_cells, sim->boundary1_cells };
+   for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
+   if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
+   if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
+   if (sim->interior_stream) HIP_CHECK(hipStreamDestroy(S(sim->interior_stream)));
+   memset(sim, 0, sizeof(*sim));
+}
+
+extern "C" void emptyHaloCellsGpu(SimGpu* sim, comdStream_t stream)
+{
+   const int nHalo = sim->boxes.nTotalBoxes - sim->boxes.nLocalBoxes;
+   HIP_CHECK(hipMemsetAsync(sim->boxes.nAtoms + sim->boxes.nLocalBoxes, 0, (size_t)nHalo * sizeof(int), S(stream)));
+}
+
+extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
+{
+   int st[4];
+   HIP_CHECK(hipDeviceSynchronize());
+   HIP_CHECK(hipMemcpy(st, sim->status, sizeof st, hipMemcpyDeviceToHost));
+   if (st[0] | st[1] | st[2]) {
+      fprintf(stderr, "Rank %d, GPU: %d, %s: ", g_rank, sim->deviceId, where);
+      if (st[0] & 1) fprintf(stderr, "a link cell overflowed its %d slots (raise --maxAtoms); ", sim->maxAtoms);
+      if (st[0] & 2) fprintf(stderr, "a cell stencil holds more atoms than the cta_cell kernel can stage; ");
+      if (st[1])     fprintf(stderr, "an atom moved beyond the halo region and was lost; ");
+      if (st[2])     fprintf(stderr, "a halo message overflowed its buffer; ");
+      fprintf(stderr, "\n");
+      exit(-1);
+   }
+}
+
+extern "C" int comdReadDeviceInt(const int* d_ptr, comdStream_t stream)
+{
+   int v = 0;
+   HIP_CHECK(hipMemcpyAsync(&v, d_ptr, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+   HIP_CHECK(hipStreamSynchronize(S(stream)));
+   return v;
+}
+
+// ---- force -------------------------------------------------------------------------------------------------------
+static LjArgs makeLjArgs(SimGpu* sim, int num_cells, int* cells_list)
+{
+   LjArgs a;
+   a.rx = sim->atoms.r.x; a.ry = sim->atoms.r.y; a.rz = sim->atoms.r.z;
+   a.fx = sim->atoms.f.x; a.fy = sim->atoms.f.y; a.fz = sim->atoms.f.z; a.e = sim->atoms.e;
+   a.nAtoms = sim->boxes.nAtoms; a.nbr = sim->neighbor_cells; a.cells = cells_list;
+   a.nCells = num_cells; a.cap = sim->maxAtoms;
+   const double sigma = sim->lj_pot.sigma, rc = sim->lj_pot.cutoff;
+   a.rc2 = rc * rc;
+   a.s6 = sigma * sigma * sigma * sigma * sigma * sigma;
+   const double rc6 = a.s6 / (a.rc2 * a.rc2 * a.rc2);
+   a.eShift = rc6 * (rc6 - 1.0);                 // POT_SHIFT 1.0
+   a.eps = sim->lj_pot.epsilon;
+   return a;
+}
+
+extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream)
+{
+   if (num_cells <= 0) return;
+   LjArgs a = makeLjArgs(sim, num_cells, cells_list);
+   ForceTimer timer(S(stream));
+   if (method == CTA_CELL) {
+      static bool attrSet = false;
+      if (!attrSet) {
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell, hipFuncAttributeMaxDynamicSharedMemorySize, LJ_CTA_LDS_BYTES));
+         attrSet = true;
+      }
+      if (27L * sim->maxAtoms > 65535) { fprintf(stderr, "ljForceGpu: cta_cell needs 27*maxAtoms < 65536\n"); exit(-1); }
+      hipLaunchKernelGGL(LJ_Force_cta_cell, dim3(num_cells), dim3(LJ_CTA_THREADS), LJ_CTA_LDS_BYTES, S(stream), a, sim->status);
+   } else {
+      const long waves = (long)num_cells * (sim->maxAtoms / 64);
+      hipLaunchKernelGGL(LJ_Force_thread_atom, dim3(ceilDiv(waves, 4)), dim3(256), 0, S(stream), a);
+   }
+   LAUNCH_CHECK();
+}
+
+extern "C" void ljForceGpu(SimGpu* sim, int interpolation, int num_cells, int* cells_list, real_t plcutoff, int method)
+{
+   (void)plcutoff;
+   if (interpolation != 0) { fprintf(stderr, "ljForceGpu: table-interpolated LJ (-I) is out of scope\n"); exit(-1); }
+   ljForceGpuAsync(sim, num_cells, cells_list, method, nullptr);
+}
+
+static EamArgs makeEamArgs(SimGpu* sim, int num_cells, int* cells_list)
+{
+   EamArgs a;
+   a.rx = sim->atoms.r.x; a.ry = sim->atoms.r.y; a.rz = sim->atoms.r.z;
+   a.fx = sim->atoms.f.x; a.fy = sim->atoms.f.y; a.fz = sim->atoms.f.z; a.e = sim->atoms.e;
+   a.rhobar = sim->eam_pot.rhobar; a.dfEmbed = sim->eam_pot.dfEmbed;
+   a.nAtoms = sim->boxes.nAtoms; a.nbr = sim->neighbor_cells; a.cells = cells_list;
+   a.nCells = num_cells; a.cap = sim->maxAtoms;
+   a.rc2 = sim->eam_pot.cutoff * sim->eam_pot.cutoff;
+   a.phi = sim->eam_pot.phi; a.rho = sim->eam_pot.rho; a.f = sim->eam_pot.f;
+   return a;
+}
+
+template <int STEP>
+static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int method, hipStream_t st)
+{
+   if (num_cells <= 0) return;
+   EamArgs a = makeEamArgs(sim, num_cells, cells_list);
+   ForceTimer timer(st);
+   if (method == CTA_CELL) {
+      const size_t lds = eamCtaLdsBytes(STEP, a.rho.n, a.phi.n);
+      static bool attrSet = false;
+      if (!attrSet) {
+         HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         attrSet = true;
+      }
+      int grid = ceilDiv(num_cells, EAM_CTA_WAVES);
+      if (grid > 2048) grid = 2048;             // persistent: 8 workgroups per CU's worth, each wave strides over cells
+      hipLaunchKernelGGL(EAM_Force_cta_cell<STEP>, dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+   } else {
+      hipLaunchKernelGGL(EAM_Force_thread_atom<STEP>, dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);
+   }
+   LAUNCH_CHECK();
+}
+
+static void checkSpline(int spline) { if (spline) { fprintf(stderr, "eamForce: spline tables (-P) are out of scope\n"); exit(-1); } }
+
+extern "C" void eamForce1GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline)
+{ checkSpline(spline); launchEamPair<1>(sim, num_cells, cells_list, method, S(stream)); }
+
+extern "C" void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline)
+{
+   checkSpline(spline); (void)method;
+   if (num_cells <= 0) return;
+   EamArgs a = makeEamArgs(sim, num_cells, cells_list);
+   ForceTimer timer(S(stream));
+   hipLaunchKernelGGL(EAM_Force_embed, dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, S(stream), a);
+   LAUNCH_CHECK();
+}
+
+extern "C" void eamForce3GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline)
+{ checkSpline(spline); launchEamPair<3>(sim, num_cells, cells_list, method, S(stream)); }
+
+extern "C" void eamForce1Gpu(SimGpu* sim, int method, int spline) { eamForce1GpuAsync(sim, sim->boxes.nLocalBoxes, nullptr, method, nullptr, spline); }
+extern "C" void eamForce2Gpu(SimGpu* sim, int method, int spline) { eamForce2GpuAsync(sim, sim->boxes.nLocalBoxes, nullptr, method, nullptr, spline); }
+extern "C" void eamForce3Gpu(SimGpu* sim, int method, int spline) { eamForce3GpuAsync(sim, sim->boxes.nLocalBoxes, nullptr, method, nullptr, spline); }
+
+extern "C" void updateNeighborsGpu(SimGpu*, int*) {}
+extern "C" void updateNeighborsGpuAsync(SimGpu*, int*, int, int*, comdStream_t) {}
+
+// ---- integrator + energy -----------------------------------------------------------------------------------------
+extern "C" void advanceVelocityGpu(SimGpu* sim, real_t dt)
+{
+   const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
+   hipLaunchKernelGGL(AdvanceVelocity, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
+                      sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z, sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z,
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dt);
+   LAUNCH_CHECK();
+}
+
+extern "C" void advancePositionGpu(SimGpu* sim, real_t dt)
+{
+   const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
+   hipLaunchKernelGGL(AdvancePosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
+                      sim->atoms.iSpecies, sim->species_mass, sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dt);
+   LAUNCH_CHECK();
+}
+
+extern "C" void computeEnergy(SimGpu* sim, real_t* eLocal)
+{
+   hipStream_t st = S(sim->boundary_stream);
+   const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
+   int blocks = ceilDiv(slots, 256);
+   if (blocks > sim->reduceBlocks) blocks = sim->reduceBlocks;
+   real_t* out = sim->reduceBuf + 2 * (size_t)sim->reduceBlocks;
+   hipLaunchKernelGGL(ReduceEnergyPartial, dim3(blocks), dim3(256), 0, st, sim->atoms.e, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
+                      sim->atoms.iSpecies, sim->species_mass, sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, sim->reduceBuf);
+   hipLaunchKernelGGL(ReduceEnergyFinal, dim3(1), dim3(256), 0, st, sim->reduceBuf, blocks, out);
+   LAUNCH_CHECK();
+   HIP_CHECK(hipMemcpyAsync(sim->pinned, out, 2 * sizeof(real_t), hipMemcpyDeviceToHost, st));
+   HIP_CHECK(hipStreamSynchronize(st));
+   eLocal[0] = sim->pinned[0]; eLocal[1] = sim->pinned[1];
+}
+
+// ---- redistribute ---------------------------------------------------------------------------------------------------
+static AtomArrays atomArrays(SimGpu* sim)
+{
+   AtomArrays at;
+   at.rx = sim->atoms.r.x; at.ry = sim->atoms.r.y; at.rz = sim->atoms.r.z;
+   at.px = sim->atoms.p.x; at.py = sim->atoms.p.y; at.pz = sim->atoms.p.z;
+   at.gid = sim->atoms.gid; at.spec = sim->atoms.iSpecies;
+   return at;
+}
+
+static int sortBlock(int cap) { return ((cap + 63) / 64) * 64; }
+
+static void launchCompactSort(SimGpu* sim, int first, int nCells, hipStream_t st)
+{
+   if (nCells <= 0) return;
+   hipLaunchKernelGGL(CompactSortCells, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), (size_t)sortBlock(sim->maxAtoms) * sizeof(int), st,
+                      atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, first, sim->maxAtoms);
+   LAUNCH_CHECK();
+}
+
+extern "C" void updateLinkCellsGpu(SimGpu* sim, comdStream_t stream)
+{
+   hipStream_t st = S(stream);
+   const int nLocal = sim->boxes.nLocalBoxes, nTotal = sim->boxes.nTotalBoxes;
+   hipLaunchKernelGGL(SnapshotCells, dim3(ceilDiv(nTotal, 256)), dim3(256), 0, st, sim->boxes.nAtoms, sim->nAtomsPrev, sim->cellDirty, nLocal, nTotal);
+   hipLaunchKernelGGL(UpdateLinkCells, dim3(ceilDiv((long)nLocal * sim->maxAtoms, 256)), dim3(256), 0, st,
+                      atomArrays(sim), sim->boxes.nAtoms, sim->nAtomsPrev, sim->cellDirty, sim->status, sim->boxes, sim->maxAtoms);
+   LAUNCH_CHECK();
+   launchCompactSort(sim, 0, nTotal, st);       // local cells that lost/gained atoms and halo cells that caught migrants
+}
+
+extern "C" void buildAtomListGpu(SimGpu*, comdStream_t) {}
+
+extern "C" void sortAtomsGpu(SimGpu* sim, comdStream_t stream)
+{
+   launchCompactSort(sim, 0, sim->boxes.nTotalBoxes, S(stream));
+}
+
+// ---- halo pack / unpack ------------------------------------------------------------------------------------------------
+extern "C" void getAtomMsgSoAPtr(char* buffer, AtomMsgSoA* m, int n)
+{
+   m->gid = (int*)(buffer + COMD_ATOM_MSG_HEADER);
+   m->type = m->gid + n;
+   m->rx = (real_t*)(m->type + n);
+   m->ry = m->rx + n; m->rz = m->ry + n; m->px = m->rz + n; m->py = m->px + n; m->pz = m->py + n;
+}
+
+extern "C" void compactCellsGpu(char* work_d, int nCells, int* d_cellList, SimGpu* sim, int* d_cellOffsets,
+                                const real_t shift[3], int capacityAtoms, comdStream_t stream)
+{
+   hipStream_t st = S(stream);
+   hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)work_d);
+   hipLaunchKernelGGL(LoadAtomsBufferPacked, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, work_d, d_cellList, d_cellOffsets, nCells,
+                      atomArrays(sim), sim->boxes.nAtoms, sim->maxAtoms, shift[0], shift[1], shift[2], capacityAtoms, sim->status);
+   LAUNCH_CHECK();
+}
+
+extern "C" int atomMsgCountGpu(SimGpu* sim, const char* msg_d, comdStream_t stream)
+{
+   (void)sim;
+   return comdReadDeviceInt((const int*)msg_d, stream);
+}
+
+extern "C" void unloadAtomsBufferToGpu(const char* msg_d, int nBuf, int maxAtomsInMsg, SimGpu* sim, comdStream_t stream)
+{
+   const int bound = nBuf >= 0 ? nBuf : maxAtomsInMsg;
+   if (bound <= 0) return;
+   hipLaunchKernelGGL(UnloadAtomsBufferPacked, dim3(ceilDiv(bound, 256)), dim3(256), 0, S(stream), msg_d, nBuf, maxAtomsInMsg,
+                      atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, sim->boxes, sim->maxAtoms);
+   LAUNCH_CHECK();
+}
+
+extern "C" void loadForceBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
+{
+   hipStream_t st = S(stream);
+   hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
+   hipLaunchKernelGGL(LoadForceBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, gpu_buf, d_cellList, d_cellOffsets,
+                      sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
+   LAUNCH_CHECK();
+}
+
+extern "C" void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
+{
+   hipStream_t st = S(stream);
+   hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
+   hipLaunchKernelGGL(UnloadForceBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, gpu_buf, d_cellList, d_cellOffsets,
+                      sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
+   LAUNCH_CHECK();
+}
+
+// ---- neighbour-list bookkeeping: out of scope, link-compatible no-ops ---------------------------------------------------
+extern "C" void emptyNeighborListGpu(SimGpu*, int) {}
+extern "C" int  neighborListUpdateRequiredGpu(SimGpu*) { return 1; }
+extern "C" int  pairlistUpdateRequiredGpu(SimGpu*) { return 1; }
+extern "C" void buildNeighborListGpu(SimGpu*, int, int) {}

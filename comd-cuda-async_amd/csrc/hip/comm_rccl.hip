@@ -1,0 +1,147 @@
+// comm_rccl.hip -- RCCL-over-xGMI transport behind CommTransport (include/comd_hip.h).
+//
+// Takes the place of the reference's comm.cc (libmp / GPUDirect-Async wrappers, :326-657) and of MPI_Sendrecv /
+// MPI_Allreduce in parallel.c:100-193.  One process per GPU; halo messages are device buffers exchanged with
+// ncclSend/ncclRecv pairs on the caller's stream.  Message sizes are data dependent and RCCL has no probe, so each
+// paired exchange first swaps the two byte counts (one int each way) and then the payloads.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <unistd.h>
+#include <sys/stat.h>
+#include <string>
+
+#include "comd_hip.h"
+
+#define HIPC(cmd) do { hipError_t e_ = (cmd); if (e_ != hipSuccess) { fprintf(stderr, "Rank %d: HIP error %s at %s:%d\n", g_rank, hipGetErrorString(e_), __FILE__, __LINE__); exit(-1); } } while (0)
+#define NCCLC(cmd) do { ncclResult_t r_ = (cmd); if (r_ != ncclSuccess) { fprintf(stderr, "Rank %d: RCCL error %s at %s:%d\n", g_rank, ncclGetErrorString(r_), __FILE__, __LINE__); exit(-1); } } while (0)
+
+static ncclComm_t g_comm = nullptr;
+static int g_rank = 0, g_nRanks = 1;
+static hipStream_t g_stream = nullptr;      // reductions / broadcasts
+static int* g_dSizes = nullptr;             // device [2]: send size, recv size
+static int* g_hSizes = nullptr;             // pinned [2]
+static void* g_dScratch = nullptr;          // device scratch for small host-buffer collectives
+static const size_t kScratchBytes = 1 << 20;
+static std::string g_idFile;
+
+static int rcclSendrecv(void*, const void* sendBuf, int sendLen, int dest, void* recvBuf, int recvCap, int source, int device, comdStream_t stream)
+{
+   hipStream_t st = (hipStream_t)stream;
+   if (!device) { fprintf(stderr, "Rank %d: RCCL transport moves device buffers only\n", g_rank); exit(-1); }
+   g_hSizes[0] = sendLen;
+   HIPC(hipMemcpyAsync(g_dSizes, g_hSizes, sizeof(int), hipMemcpyHostToDevice, st));
+   NCCLC(ncclGroupStart());
+   NCCLC(ncclSend(g_dSizes, 1, ncclInt, dest, g_comm, st));
+   NCCLC(ncclRecv(g_dSizes + 1, 1, ncclInt, source, g_comm, st));
+   NCCLC(ncclGroupEnd());
+   HIPC(hipMemcpyAsync(g_hSizes + 1, g_dSizes + 1, sizeof(int), hipMemcpyDeviceToHost, st));
+   HIPC(hipStreamSynchronize(st));
+   const int recvLen = g_hSizes[1];
+   if (recvLen > recvCap) { fprintf(stderr, "Rank %d: incoming halo message (%d B) exceeds the buffer (%d B)\n", g_rank, recvLen, recvCap); exit(-1); }
+   NCCLC(ncclGroupStart());
+   if (sendLen > 0) NCCLC(ncclSend(sendBuf, (size_t)sendLen, ncclChar, dest, g_comm, st));
+   if (recvLen > 0) NCCLC(ncclRecv(recvBuf, (size_t)recvLen, ncclChar, source, g_comm, st));
+   NCCLC(ncclGroupEnd());
+   return recvLen;
+}
+
+static void rcclAllreduce(void*, void* buf, int count, int dtype)
+{
+   const size_t bytes = (size_t)count * (dtype == 1 ? sizeof(double) : sizeof(int));
+   if (bytes > kScratchBytes) { fprintf(stderr, "Rank %d: allreduce of %zu bytes exceeds the scratch buffer\n", g_rank, bytes); exit(-1); }
+   HIPC(hipMemcpyAsync(g_dScratch, buf, bytes, hipMemcpyHostToDevice, g_stream));
+   NCCLC(ncclAllReduce(g_dScratch, g_dScratch, (size_t)count, dtype == 1 ? ncclDouble : ncclInt, dtype == 2 ? ncclMax : ncclSum, g_comm, g_stream));
+   HIPC(hipMemcpyAsync(buf, g_dScratch, bytes, hipMemcpyDeviceToHost, g_stream));
+   HIPC(hipStreamSynchronize(g_stream));
+}
+
+static void rcclBcast(void*, void* buf, int len, int root)
+{
+   if ((size_t)len > kScratchBytes) { fprintf(stderr, "Rank %d: bcast of %d bytes exceeds the scratch buffer\n", g_rank, len); exit(-1); }
+   HIPC(hipMemcpyAsync(g_dScratch, buf, (size_t)len, hipMemcpyHostToDevice, g_stream));
+   NCCLC(ncclBroadcast(g_dScratch, g_dScratch, (size_t)len, ncclChar, root, g_comm, g_stream));
+   HIPC(hipMemcpyAsync(buf, g_dScratch, (size_t)len, hipMemcpyDeviceToHost, g_stream));
+   HIPC(hipStreamSynchronize(g_stream));
+}
+
+static void rcclBarrier(void*)
+{
+   int one = 1;
+   rcclAllreduce(nullptr, &one, 1, 0);
+}
+
+extern "C" int comdCommGetUniqueId(char* id128)
+{
+   static_assert(sizeof(ncclUniqueId) <= COMD_UNIQUE_ID_BYTES, "unique id larger than the ABI slot");
+   ncclUniqueId id;
+   if (ncclGetUniqueId(&id) != ncclSuccess) return -1;
+   memset(id128, 0, COMD_UNIQUE_ID_BYTES);
+   memcpy(id128, &id, sizeof id);
+   return 0;
+}
+
+extern "C" int comdCommInitRank(const char* id128, int rank, int nRanks, CommTransport* out)
+{
+   g_rank = rank; g_nRanks = nRanks;
+   ncclUniqueId id;
+   memcpy(&id, id128, sizeof id);
+   NCCLC(ncclCommInitRank(&g_comm, nRanks, id, rank));
+   HIPC(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+   HIPC(hipMalloc((void**)&g_dSizes, 2 * sizeof(int)));
+   HIPC(hipHostMalloc((void**)&g_hSizes, 2 * sizeof(int), hipHostMallocDefault));
+   HIPC(hipMalloc(&g_dScratch, kScratchBytes));
+   out->ctx = nullptr;
+   out->sendrecv = rcclSendrecv;
+   out->allreduce = rcclAllreduce;
+   out->bcast = rcclBcast;
+   out->barrier = rcclBarrier;
+   return 0;
+}
+
+extern "C" int comdCommInitFromEnv(CommTransport* out, int* rank, int* nRanks, int* localRank)
+{
+   const char* r = getenv("RANK"); const char* w = getenv("WORLD_SIZE"); const char* l = getenv("LOCAL_RANK");
+   if (!r || !w) return -1;
+   *rank = atoi(r); *nRanks = atoi(w); *localRank = l ? atoi(l) : *rank;
+   const char* dir = getenv("COMD_RDZV_DIR"); const char* port = getenv("MASTER_PORT"); const char* run = getenv("TORCHELASTIC_RUN_ID");
+   g_idFile = std::string(dir ? dir : "/tmp") + "/comd_rccl_id_" + (port ? port : "29500") + "_" + (run ? run : "0");
+   char id[COMD_UNIQUE_ID_BYTES];
+   if (*rank == 0) {
+      unlink(g_idFile.c_str());
+      if (comdCommGetUniqueId(id) != 0) return -1;
+      std::string tmp = g_idFile + ".tmp";
+      FILE* f = fopen(tmp.c_str(), "wb");
+      if (!f || fwrite(id, 1, sizeof id, f) != sizeof id) return -1;
+      fclose(f);
+      if (rename(tmp.c_str(), g_idFile.c_str()) != 0) return -1;
+   } else {
+      const time_t start = time(nullptr);
+      for (int tries = 0; ; ++tries) {
+         struct stat sb;
+         if (stat(g_idFile.c_str(), &sb) == 0 && sb.st_size == (off_t)sizeof id && sb.st_mtime + 120 >= start) {
+            FILE* f = fopen(g_idFile.c_str(), "rb");
+            if (f && fread(id, 1, sizeof id, f) == sizeof id) { fclose(f); break; }
+            if (f) fclose(f);
+         }
+         if (tries > 1200) { fprintf(stderr, "Rank %d: timed out waiting for %s\n", *rank, g_idFile.c_str()); return -1; }
+         usleep(100000);
+      }
+   }
+   return comdCommInitRank(id, *rank, *nRanks, out);
+}
+
+extern "C" void comdCommFinalize(void)
+{
+   if (!g_comm) return;
+   rcclBarrier(nullptr);
+   if (g_rank == 0 && !g_idFile.empty()) unlink(g_idFile.c_str());
+   ncclCommDestroy(g_comm); g_comm = nullptr;
+   if (g_dSizes) (void)hipFree(g_dSizes);
+   if (g_hSizes) (void)hipHostFree(g_hSizes);
+   if (g_dScratch) (void)hipFree(g_dScratch);
+   if (g_stream) (void)hipStreamDestroy(g_stream);
+   g_dSizes = nullptr; g_hSizes = nullptr; g_dScratch = nullptr; g_stream = nullptr;
+}

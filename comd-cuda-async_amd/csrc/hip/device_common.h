@@ -1,0 +1,103 @@
+// device_common.h -- wave64 helpers shared by the gfx950 kernels.
+//
+// Stands where the reference's gpu_common.h does (interpolate :48-86, warp_reduce :252-278,
+// PTX laneid/bfi :231-236/:316-321), re-expressed for CDNA4: 64-lane wavefronts, DPP/bpermute
+// cross-lane moves, v_rcp_f64 + Newton instead of rsqrt.approx PTX.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include "comd_hip.h"
+#include "comd_geometry.h"
+
+#define WAVE 64
+
+__device__ __forceinline__ int laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+// 1/x to fp64 round-off: v_rcp_f64 is good to ~2^-24 relative, two Newton steps square that twice.
+__device__ __forceinline__ double rcp64(double x)
+{
+   double y = __builtin_amdgcn_rcp(x);
+   double e = __builtin_fma(-x, y, 1.0);
+   y = __builtin_fma(y, e, y);
+   e = __builtin_fma(-x, y, 1.0);
+   y = __builtin_fma(y, e, y);
+   return y;
+}
+
+// 1/sqrt(x) to fp64 round-off from v_rsq_f64 (~2^-24) with two Newton steps.
+__device__ __forceinline__ double rsqrt64(double x)
+{
+   double y = __builtin_amdgcn_rsq(x);
+   double h = 0.5 * x;
+   y = y * __builtin_fma(-h * y, y, 1.5);
+   y = y * __builtin_fma(-h * y, y, 1.5);
+   return y;
+}
+
+// 64-bit cross-lane read through ds_bpermute (two dword permutes); srcLane in [0,63].
+__device__ __forceinline__ double bpermute64(double v, int srcLane)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_ds_bpermute(srcLane << 2, lo);
+   hi = __builtin_amdgcn_ds_bpermute(srcLane << 2, hi);
+   return __hiloint2double(hi, lo);
+}
+
+// butterfly sum over the 64 lanes; every lane ends with the total, in a fixed order
+__device__ __forceinline__ double waveSum(double v)
+{
+#pragma unroll
+   for (int m = 32; m >= 1; m >>= 1) v += bpermute64(v, laneId() ^ m);
+   return v;
+}
+
+__device__ __forceinline__ int waveSumInt(int v)
+{
+#pragma unroll
+   for (int m = 32; m >= 1; m >>= 1) v += __builtin_amdgcn_ds_bpermute((laneId() ^ m) << 2, v);
+   return v;
+}
+
+// Blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8).  Give each XCD one contiguous run
+// of the logical grid so that blocks sharing neighbour cells also share an L2 (bijective for any grid size).
+__device__ __forceinline__ int xcdRemap(int bid, int nBlocks)
+{
+   const int nx = 8;
+   int q = nBlocks / nx, r = nBlocks % nx, xcd = bid % nx, k = bid / nx;
+   int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+   return start + k;
+}
+
+// Quadratic table interpolation, value + derivative (reference gpu_common.h:48-86; host eam.c:557-579).
+// `v` points at the padded table: v[0] is the leading pad, v[i+1] is sample i.
+struct TableView { const double* v; double x0, xn, invDx, invDxHalf, invDxXx0; };
+
+__device__ __forceinline__ TableView makeTable(const InterpolationObjectGpu& t, const double* values)
+{
+   TableView tv; tv.v = values; tv.x0 = t.x0; tv.xn = t.xn; tv.invDx = t.invDx; tv.invDxHalf = t.invDxHalf; tv.invDxXx0 = t.invDxXx0;
+   return tv;
+}
+
+__device__ __forceinline__ void interpolate(const TableView& t, double r, double& f, double& df)
+{
+   r = fmax(r, t.x0);
+   r = fmin(r, t.xn);
+   r = r * t.invDx - t.invDxXx0;
+   double ri = floor(r);
+   int ii = (int)ri;
+   r -= ri;
+   double v0 = t.v[ii], v1 = t.v[ii + 1], v2 = t.v[ii + 2], v3 = t.v[ii + 3];
+   double g1 = v2 - v0, g2 = v3 - v1;
+   f  = v1 + 0.5 * r * (g1 + r * (v2 + v0 - 2.0 * v1));
+   df = (g1 + r * (g2 - g1)) * t.invDxHalf;
+}
+
+__device__ __forceinline__ CellGeom makeGeom(const LinkCellGpu& b)
+{
+   CellGeom c;
+   for (int a = 0; a < 3; ++a) { c.g[a] = b.gridSize[a]; c.lmin[a] = b.localMin[a]; c.lmax[a] = b.localMax[a]; c.inv[a] = b.invBoxSize[a]; }
+   c.nLocal = b.nLocalBoxes; c.nTotal = b.nTotalBoxes;
+   return c;
+}

@@ -1,0 +1,245 @@
+// step_kernels.h -- integrator, energy reduction, link-cell redistribution and halo pack/unpack kernels.
+//
+// Behaviour of the reference's gpu_timestep.h:31-62 (AdvanceVelocity/AdvancePosition), gpu_reduce.h:32-98
+// (ReduceEnergy), gpu_redistribute.h:135-268 (UpdateLinkCells/CompactAtoms), :376-402 (LoadAtomsBufferPacked),
+// :499-620 (computeBoxIds/computeOffsets/UnloadAtomsBufferPacked), :638-672 (Load/UnloadForceBuffer) and
+// :682-848 (gid sort), restructured for slot-addressed cells (cell*cap + i) on wave64 hardware:
+//  - no a_list indirection: kernels run over slots and mask by nAtoms[cell];
+//  - moved atoms are appended to their new cell with one atomic, the vacated slot is marked gid = -1, and one
+//    workgroup per changed cell squeezes the holes AND restores ascending-gid order in a single pass
+//    (rank sort in LDS) -- the reference compacts with one thread per cell and sorts <= 32 atoms per cell;
+//  - energy is reduced in two deterministic stages (no fp64 atomics).
+#pragma once
+#include "device_common.h"
+
+// ---- integrator -------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void AdvanceVelocity(double* __restrict__ px, double* __restrict__ py, double* __restrict__ pz,
+                     const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
+                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double dt)
+{
+   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int c = (int)(tid / cap);
+   if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
+   px[tid] += dt * fx[tid]; py[tid] += dt * fy[tid]; pz[tid] += dt * fz[tid];
+}
+
+__global__ __launch_bounds__(256)
+void AdvancePosition(double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
+                     const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz,
+                     const int* __restrict__ iSpecies, const double* __restrict__ speciesMass,
+                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double dt)
+{
+   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int c = (int)(tid / cap);
+   if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
+   const double invMass = 1.0 / speciesMass[iSpecies[tid]];  // same expression order as timestep.c:168-173
+   rx[tid] += dt * px[tid] * invMass; ry[tid] += dt * py[tid] * invMass; rz[tid] += dt * pz[tid] * invMass;
+}
+
+// ---- energy: stage 1 = per-block partial sums in a fixed order, stage 2 = one block adds the partials --------
+__global__ __launch_bounds__(256)
+void ReduceEnergyPartial(const double* __restrict__ e, const double* __restrict__ px, const double* __restrict__ py,
+                         const double* __restrict__ pz, const int* __restrict__ iSpecies,
+                         const double* __restrict__ speciesMass, const int* __restrict__ nAtoms,
+                         int nLocalBoxes, int cap, double* __restrict__ partial)
+{
+   __shared__ double sE[4], sK[4];
+   double accE = 0.0, accK = 0.0;
+   const long nSlots = (long)nLocalBoxes * cap;
+   for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSlots; s += (long)gridDim.x * blockDim.x) {
+      const int c = (int)(s / cap);
+      if ((int)(s - (long)c * cap) < nAtoms[c]) {
+         accE += e[s];
+         accK += (px[s]*px[s] + py[s]*py[s] + pz[s]*pz[s]) * (0.5 / speciesMass[iSpecies[s]]);
+      }
+   }
+   accE = waveSum(accE); accK = waveSum(accK);
+   const int wave = threadIdx.x >> 6;
+   if ((threadIdx.x & 63) == 0) { sE[wave] = accE; sK[wave] = accK; }
+   __syncthreads();
+   if (threadIdx.x == 0) {
+      partial[2 * blockIdx.x]     = (sE[0] + sE[1]) + (sE[2] + sE[3]);
+      partial[2 * blockIdx.x + 1] = (sK[0] + sK[1]) + (sK[2] + sK[3]);
+   }
+}
+
+__global__ __launch_bounds__(256)
+void ReduceEnergyFinal(const double* __restrict__ partial, int nPartial, double* __restrict__ out)
+{
+   __shared__ double sE[4], sK[4];
+   double accE = 0.0, accK = 0.0;
+   for (int i = threadIdx.x; i < nPartial; i += blockDim.x) { accE += partial[2*i]; accK += partial[2*i + 1]; }
+   accE = waveSum(accE); accK = waveSum(accK);
+   const int wave = threadIdx.x >> 6;
+   if ((threadIdx.x & 63) == 0) { sE[wave] = accE; sK[wave] = accK; }
+   __syncthreads();
+   if (threadIdx.x == 0) { out[0] = (sE[0] + sE[1]) + (sE[2] + sE[3]); out[1] = (sK[0] + sK[1]) + (sK[2] + sK[3]); }
+}
+
+// ---- redistribution -------------------------------------------------------------------------------------
+// snapshot local occupancies, empty the halo cells (timestep.c:224), clear dirty flags
+__global__ __launch_bounds__(256)
+void SnapshotCells(int* __restrict__ nAtoms, int* __restrict__ nAtomsPrev, int* __restrict__ dirty, int nLocal, int nTotal)
+{
+   const int c = blockIdx.x * blockDim.x + threadIdx.x;
+   if (c >= nTotal) return;
+   if (c < nLocal) nAtomsPrev[c] = nAtoms[c]; else { nAtoms[c] = 0; nAtomsPrev[c] = 0; }
+   dirty[c] = 0;
+}
+
+struct AtomArrays {
+   double *rx, *ry, *rz, *px, *py, *pz;
+   int *gid, *spec;
+};
+
+// gpu_redistribute.h:135-180 UpdateLinkCells: every local atom re-derives its cell from its coordinates; movers
+// are appended to the destination cell (local or halo) and leave a hole (gid = -1) behind.
+__global__ __launch_bounds__(256)
+void UpdateLinkCells(AtomArrays at, int* __restrict__ nAtoms, const int* __restrict__ nAtomsPrev,
+                     int* __restrict__ dirty, int* __restrict__ status, LinkCellGpu boxes, int cap)
+{
+   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int c = (int)(tid / cap);
+   if (c >= boxes.nLocalBoxes || (int)(tid - (long)c * cap) >= nAtomsPrev[c]) return;
+   const CellGeom g = makeGeom(boxes);
+   const double x = at.rx[tid], y = at.ry[tid], z = at.rz[tid];
+   const int nb = comdBoxFromCoord(&g, x, y, z);
+   if (nb == c) return;
+   if (!comdCoordInHalo(&g, x, y, z)) { atomicOr(&status[1], 1); return; }     // flew past the halo: lost
+   const int slot = atomicAdd(&nAtoms[nb], 1);
+   if (slot >= cap) { atomicOr(&status[0], 1); return; }
+   const size_t d = (size_t)nb * cap + slot;
+   at.rx[d] = x; at.ry[d] = y; at.rz[d] = z;
+   at.px[d] = at.px[tid]; at.py[d] = at.py[tid]; at.pz[d] = at.pz[tid];
+   at.gid[d] = at.gid[tid]; at.spec[d] = at.spec[tid];
+   at.gid[tid] = -1;
+   dirty[c] = 1; dirty[nb] = 1;
+}
+
+// One workgroup per cell in [first, first+n): if the cell is dirty, drop holes and rewrite the survivors in
+// ascending-gid order (rank sort: rank = number of smaller keys; gids are unique).  blockDim.x >= cap.
+__global__
+void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int* __restrict__ status,
+                      int first, int cap)
+{
+   extern __shared__ int sKey[];
+   const int c = first + blockIdx.x;
+   if (!dirty[c]) return;
+   int n = nAtoms[c];
+   if (n > cap) n = cap;                                  // overflow already flagged by the writer
+   const int t = threadIdx.x;
+   const size_t o = (size_t)c * cap + t;
+   int key = 0x7fffffff, spec = 0;
+   double x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
+   if (t < n) {
+      int g = at.gid[o];
+      if (g >= 0) { key = g; spec = at.spec[o]; x = at.rx[o]; y = at.ry[o]; z = at.rz[o]; px = at.px[o]; py = at.py[o]; pz = at.pz[o]; }
+   }
+   if (t < cap) sKey[t] = key;
+   __syncthreads();
+   int rank = 0, live = 0;
+   for (int j = 0; j < n; ++j) { int kj = sKey[j]; rank += (kj < key); live += (kj != 0x7fffffff); }
+   __syncthreads();
+   if (key != 0x7fffffff) {
+      const size_t d = (size_t)c * cap + rank;
+      at.gid[d] = key; at.spec[d] = spec;
+      at.rx[d] = x; at.ry[d] = y; at.rz[d] = z; at.px[d] = px; at.py[d] = py; at.pz[d] = pz;
+   }
+   if (t == 0) { nAtoms[c] = live; dirty[c] = 0; }
+}
+
+// ---- exclusive scan of nAtoms over a cell list (gpu_kernels.cu:357-407 fill + scan) ---------------------
+// single workgroup of 1024 threads; out[i] = sum_{k<i} nAtoms[list[k]], out[n] = total; also copied to *total.
+__global__ __launch_bounds__(1024)
+void ScanCellCounts(const int* __restrict__ nAtoms, const int* __restrict__ list, int n, int* __restrict__ out, int* __restrict__ total)
+{
+   __shared__ int sWave[16];
+   __shared__ int sCarry;
+   if (threadIdx.x == 0) sCarry = 0;
+   __syncthreads();
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   for (int base = 0; base < n; base += 1024) {
+      const int i = base + threadIdx.x;
+      const int v = i < n ? nAtoms[list ? list[i] : i] : 0;
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+      if (lane == 63) sWave[wave] = incl;
+      __syncthreads();
+      int wavePrefix = 0;
+      for (int w = 0; w < wave; ++w) wavePrefix += sWave[w];
+      const int carry = sCarry;
+      if (i < n) out[i] = carry + wavePrefix + incl - v;
+      __syncthreads();
+      if (threadIdx.x == 1023) sCarry = carry + wavePrefix + incl;
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) { out[n] = sCarry; if (total) *total = sCarry; }
+}
+
+// ---- atom halo message -----------------------------------------------------------------------------------
+// gpu_redistribute.h:376-402 LoadAtomsBufferPacked: one workgroup per listed cell gathers its atoms into the SoA
+// message at offsets[cell]; positions are shifted across the periodic boundary.  blockDim.x >= cap.
+__global__
+void LoadAtomsBufferPacked(char* __restrict__ msg, const int* __restrict__ list, const int* __restrict__ offsets,
+                           int nCells, AtomArrays at, const int* __restrict__ nAtoms, int cap,
+                           double sx, double sy, double sz, int capacityAtoms, int* __restrict__ status)
+{
+   const int c = list[blockIdx.x];
+   const int t = threadIdx.x;
+   const int n = offsets[nCells];
+   if (n > capacityAtoms) { if (blockIdx.x == 0 && t == 0) atomicOr(&status[2], 1); return; }
+   if (t >= nAtoms[c]) return;
+   const size_t o = (size_t)c * cap + t;
+   const int d = offsets[blockIdx.x] + t;
+   int* mg = (int*)(msg + COMD_ATOM_MSG_HEADER);
+   int* mt = mg + n;
+   double* m = (double*)(mt + n);
+   mg[d] = at.gid[o]; mt[d] = at.spec[o];
+   m[d] = at.rx[o] + sx; m[n + d] = at.ry[o] + sy; m[2*(size_t)n + d] = at.rz[o] + sz;
+   m[3*(size_t)n + d] = at.px[o]; m[4*(size_t)n + d] = at.py[o]; m[5*(size_t)n + d] = at.pz[o];
+}
+
+// gpu_redistribute.h:499-620: every received atom finds its cell from its coordinates and is appended there.
+__global__ __launch_bounds__(256)
+void UnloadAtomsBufferPacked(const char* __restrict__ msg, int nBuf, int capacityAtoms, AtomArrays at, int* __restrict__ nAtoms,
+                             int* __restrict__ dirty, int* __restrict__ status, LinkCellGpu boxes, int cap)
+{
+   const int n = nBuf >= 0 ? nBuf : ((const int*)msg)[0];
+   if (n < 0 || n > capacityAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
+   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+   if (i >= n) return;
+   const int* mg = (const int*)(msg + COMD_ATOM_MSG_HEADER);
+   const int* mt = mg + n;
+   const double* m = (const double*)(mt + n);
+   const double x = m[i], y = m[n + i], z = m[2*(size_t)n + i];
+   const CellGeom g = makeGeom(boxes);
+   if (!comdCoordInHalo(&g, x, y, z)) { atomicOr(&status[1], 1); return; }
+   const int c = comdBoxFromCoord(&g, x, y, z);
+   const int slot = atomicAdd(&nAtoms[c], 1);
+   if (slot >= cap) { atomicOr(&status[0], 1); return; }
+   const size_t d = (size_t)c * cap + slot;
+   at.gid[d] = mg[i]; at.spec[d] = mt[i];
+   at.rx[d] = x; at.ry[d] = y; at.rz[d] = z;
+   at.px[d] = m[3*(size_t)n + i]; at.py[d] = m[4*(size_t)n + i]; at.pz[d] = m[5*(size_t)n + i];
+   dirty[c] = 1;
+}
+
+// ---- EAM force (dfEmbed) halo message: gpu_redistribute.h:638-672 ---------------------------------------------
+// blockDim.x >= cap; one workgroup per listed cell; positional (both sides hold the cell in gid order).
+__global__
+void LoadForceBuffer(double* __restrict__ buf, const int* __restrict__ list, const int* __restrict__ offsets,
+                     const double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap)
+{
+   const int c = list[blockIdx.x];
+   if ((int)threadIdx.x < nAtoms[c]) buf[offsets[blockIdx.x] + threadIdx.x] = dfEmbed[(size_t)c * cap + threadIdx.x];
+}
+
+__global__
+void UnloadForceBuffer(const double* __restrict__ buf, const int* __restrict__ list, const int* __restrict__ offsets,
+                       double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap)
+{
+   const int c = list[blockIdx.x];
+   if ((int)threadIdx.x < nAtoms[c]) dfEmbed[(size_t)c * cap + threadIdx.x] = buf[offsets[blockIdx.x] + threadIdx.x];
+}

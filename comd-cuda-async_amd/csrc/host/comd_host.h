@@ -1,0 +1,267 @@
+/* comd_host.h -- host side (plain C11) of the MI355X CoMD hot path.
+ *
+ * Mirrors the reference's operator surface so the loop reads like src-mpi/timestep.c:
+ *   BasePotential {force, print, destroy}      CoMDTypes.h:42-53
+ *   HaloExchange  {loadBuffer, unloadBuffer, destroy}   haloExchange.h:84-104
+ *   timestep(), computeForce(), redistributeAtoms(), kineticEnergyGpu()   timestep.c:48-276
+ * and calls the device only through include/comd_hip.h.  No HIP headers here.
+ */
+#ifndef COMD_HOST_H
+#define COMD_HOST_H
+
+#include <stdio.h>
+#include <stdint.h>
+#include "comd_hip.h"
+#include "comd_geometry.h"
+
+#define screenOut stdout
+
+/* ---- constants.h:14-39 ---- */
+#define amuInKilograms  1.660538921e-27
+#define fsInSeconds     1.0e-15
+#define AngsInMeters    1.0e-10
+#define eVInJoules      1.602176565e-19
+static const double amuToInternalMass = amuInKilograms * AngsInMeters * AngsInMeters / (fsInSeconds * fsInSeconds * eVInJoules);
+static const double kB_eV = 8.6173324e-5;
+static const double hartreeToEv = 27.21138505;
+static const double bohrToAngs = 0.52917721092;
+
+/* ---- command line: mycommand.h ---- */
+typedef struct CommandSt {
+   char potDir[1024], potName[1024], potType[1024], method[1024];
+   int doeam, nx, ny, nz, xproc, yproc, zproc, nSteps, printRate;
+   double dt, lat, temperature, initialDelta, relativeSkinDistance;
+   int doHilbert, gpuAsync, gpuProfile, ljInterpolation, spline, usePairlist;
+   int maxAtoms;          /* extension: link-cell slot capacity, 0 = choose from the lattice (reference: -DMAXATOMS) */
+   int quiet;             /* extension: suppress the stdout report (library use) */
+} Command;
+
+Command parseCommandLine(int argc, char** argv);
+void printCmdYaml(FILE* file, Command* cmd);
+
+/* ---- parallel layer: parallel.h.  One process per GPU; the transport is pluggable. ---- */
+/* CommTransport: include/comd_hip.h */
+
+void initParallel(int rank, int nRanks, const CommTransport* transport);   /* parallel.c:57-64 */
+void destroyParallel(void);
+int  getNRanks(void);
+int  getMyRank(void);
+int  printRank(void);
+void barrierParallel(void);
+void timestampBarrier(const char* msg);
+int  sendReceiveParallel(void* sendBuf, int sendLen, int dest, void* recvBuf, int recvLen, int source);
+int  sendReceiveDevice(void* sendBuf, int sendLen, int dest, void* recvBuf, int recvLen, int source, comdStream_t stream);
+void addIntParallel(int* sendBuf, int* recvBuf, int count);
+void addRealParallel(real_t* sendBuf, real_t* recvBuf, int count);
+void addDoubleParallel(double* sendBuf, double* recvBuf, int count);
+void maxIntParallel(int* sendBuf, int* recvBuf, int count);
+void bcastParallel(void* buf, int len, int root);
+
+/* ---- decomposition.h ---- */
+typedef struct DomainSt {
+   int procGrid[3], procCoord[3];
+   real_t globalMin[3], globalMax[3], globalExtent[3];
+   real_t localMin[3], localMax[3], localExtent[3];
+} Domain;
+Domain* initDecomposition(int xproc, int yproc, int zproc, const real_t globalExtent[3]);
+int processorNum(Domain* domain, int dix, int diy, int diz);
+
+/* ---- linkCells.h ---- */
+typedef struct LinkCellSt {
+   int gridSize[3];
+   int nLocalBoxes, nHaloBoxes, nTotalBoxes;
+   real_t localMin[3], localMax[3], boxSize[3], invBoxSize[3];
+   int* nAtoms;           /* host copy; refreshed from the device by sumAtoms */
+   int maxAtoms;          /* slot capacity per cell */
+   CellGeom geom;
+} LinkCell;
+LinkCell* initLinkCells(const Domain* domain, real_t cutoff);
+void destroyLinkCells(LinkCell** boxes);
+int getNeighborBoxes(LinkCell* boxes, int iBox, int* nbrBoxes);
+int getBoxFromTuple(LinkCell* boxes, int x, int y, int z);
+int getBoxFromCoord(LinkCell* boxes, const real_t rr[3]);
+int maxOccupancy(LinkCell* boxes);
+
+/* ---- initAtoms.h ---- */
+typedef struct AtomsSt {
+   int nLocal, nGlobal;
+   HostAtoms h;           /* slot arrays, cell*maxAtoms + i */
+} Atoms;
+struct SimFlatSt;
+Atoms* initAtoms(LinkCell* boxes);
+void destroyAtoms(Atoms* atoms);
+/* pass 1 (atoms == NULL storage): returns the largest per-cell count the lattice produces on this rank */
+int  countFccLattice(int nx, int ny, int nz, real_t lat, const Domain* domain, LinkCell* boxes);
+void createFccLattice(int nx, int ny, int nz, real_t lat, struct SimFlatSt* s);
+void setTemperature(struct SimFlatSt* s, real_t temperature);
+void randomDisplacements(struct SimFlatSt* s, real_t delta);
+int  putAtomInBox(LinkCell* boxes, Atoms* atoms, int gid, int iType, real_t x, real_t y, real_t z, real_t px, real_t py, real_t pz);
+void kineticEnergyHost(struct SimFlatSt* s);   /* timestep.c:109-133, used during initialisation only */
+
+/* ---- random.h ---- */
+real_t   gasdev(uint64_t* seed);
+double   lcg61(uint64_t* seed);
+uint64_t mkSeed(uint32_t id, uint32_t callSite);
+
+/* ---- potentials: CoMDTypes.h:42-53, 140-201 ---- */
+typedef struct BasePotentialSt {
+   real_t cutoff, mass, lat;
+   char latticeType[8];
+   char name[3];
+   int atomicNo;
+   int  (*force)(struct SimFlatSt* s);
+   void (*print)(FILE* file, struct BasePotentialSt* pot);
+   void (*destroy)(struct BasePotentialSt** pot);
+} BasePotential;
+
+typedef struct LjPotentialSt {
+   real_t cutoff, mass, lat; char latticeType[8]; char name[3]; int atomicNo;
+   int  (*force)(struct SimFlatSt* s);
+   void (*print)(FILE* file, BasePotential* pot);
+   void (*destroy)(BasePotential** pot);
+   real_t sigma, epsilon;
+} LjPotential;
+
+typedef struct InterpolationObjectSt {
+   int n; real_t x0, invDx; real_t* values; real_t invDxXx0;
+} InterpolationObject;
+
+struct HaloExchangeSt;
+typedef struct EamPotentialSt {
+   real_t cutoff, mass, lat; char latticeType[8]; char name[3]; int atomicNo;
+   int  (*force)(struct SimFlatSt* s);
+   void (*print)(FILE* file, BasePotential* pot);
+   void (*destroy)(BasePotential** pot);
+   InterpolationObject *phi, *rho, *f;
+   struct HaloExchangeSt* forceExchange;
+} EamPotential;
+
+BasePotential* initLjPot(void);
+BasePotential* initEamPot(const char* dir, const char* file, const char* type);
+void interpolate(InterpolationObject* table, real_t r, real_t* f, real_t* df);
+
+typedef struct SpeciesDataSt { char name[3]; int atomicNo; real_t mass; } SpeciesData;
+typedef struct ValidateSt { double eTot0; int nAtoms0; } Validate;
+
+/* ---- halo exchange: haloExchange.h ---- */
+enum HaloFaceOrder { HALO_X_MINUS, HALO_X_PLUS, HALO_Y_MINUS, HALO_Y_PLUS, HALO_Z_MINUS, HALO_Z_PLUS };
+enum HaloAxisOrder { HALO_X_AXIS, HALO_Y_AXIS, HALO_Z_AXIS };
+
+typedef struct HaloExchangeSt {
+   int nbrRank[6];
+   int bufCapacity;                       /* bytes per message buffer */
+   int (*loadBuffer)(void* parms, void* data, int face, char* buf);
+   void (*unloadBuffer)(void* parms, void* data, int face, int bufSize, char* buf);
+   void (*destroy)(void* parms);
+   void* parms;
+   int type;                              /* 0 atoms, 1 force */
+   int deviceBuffers;                     /* 1: the four buffers are device memory */
+   char *sendBufM, *sendBufP, *recvBufM, *recvBufP;
+} HaloExchange;
+
+typedef struct AtomExchangeParmsSt {
+   int nCells[6];
+   int* cellList[6];                      /* host */
+   int* cellListGpu[6];                   /* device */
+   int* d_cellOffsets;                    /* device scratch, max nCells + 1 */
+   real_t shift[6][3];                    /* pbcFactor * globalExtent */
+   int capacityAtoms;
+} AtomExchangeParms;
+
+typedef struct ForceExchangeParmsSt {
+   int nCells[6];
+   int *sendCells[6], *recvCells[6];
+   int *sendCellsGpu[6], *recvCellsGpu[6];
+   int* d_cellOffsets;
+   int capacityAtoms;
+} ForceExchangeParms;
+
+HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice);
+HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice);
+void destroyHaloExchange(HaloExchange** haloExchange);
+void haloExchange(HaloExchange* haloExchange, void* data);
+void exchangeData(HaloExchange* haloExchange, void* data, int iAxis);
+int* mkAtomCellList(LinkCell* boxes, enum HaloFaceOrder iFace, int nCells);
+int* mkForceSendCellList(LinkCell* boxes, int face, int nCells);
+int* mkForceRecvCellList(LinkCell* boxes, int face, int nCells);
+
+/* ---- simulation: CoMDTypes.h:75-135 ---- */
+typedef struct SimFlatSt {
+   int nSteps, printRate;
+   double dt;
+   Domain* domain;
+   LinkCell* boxes;
+   Atoms* atoms;
+   SpeciesData* species;
+   real_t ePotential, eKinetic;
+   BasePotential* pot;
+   HaloExchange* atomExchange;
+   SimGpu gpu;
+   int method;
+   int n_boundary_cells, n_boundary1_cells;
+   int *boundary_cells_h, *interior_cells_h, *boundary1_cells_h;
+   int gpuAsync, gpuProfile;
+   int ljInterpolation, spline, usePairlist;
+   real_t skinDistance;
+   int quiet, cmdDoeam;
+   int iStepPrev, firstPrint;       /* printThings state (static locals in CoMD.c:466-467) */
+} SimFlat;
+
+SimFlat* initSimulation(Command cmd);
+SimFlat* initSimulationHost(Command cmd);      /* no device: lattice, momenta, link cells only */
+void destroySimulation(SimFlat** ps);
+void sumAtoms(SimFlat* s);
+void printThings(SimFlat* s, int iStep, double elapsedTime);
+Validate* initValidate(SimFlat* s);
+void validateResult(const Validate* val, SimFlat* sim);
+void printSimulationDataYaml(FILE* file, SimFlat* s);
+void setBoundaryCellsHost(SimFlat* sim, HaloExchange* hh);
+
+/* ---- timestep.h ---- */
+double timestep(SimFlat* s, int n, real_t dt);
+void computeForce(SimFlat* s);
+void kineticEnergyGpu(SimFlat* s);
+void redistributeAtoms(SimFlat* sim);
+
+/* ---- performanceTimers.h ---- */
+enum TimerHandle { totalTimer, loopTimer, timestepTimer, positionTimer, velocityTimer, redistributeTimer, atomHaloTimer,
+                   computeForceTimer, eamHaloTimer, commHaloTimer, commReduceTimer, neighborListBuildTimer, numberOfTimers };
+void profileStart(enum TimerHandle handle);
+void profileStop(enum TimerHandle handle);
+double getElapsedTime(enum TimerHandle handle);
+void resetTimers(void);
+void printPerformanceResults(int nGlobalAtoms, int printRate);
+void printPerformanceResultsYaml(FILE* file);
+#define startTimer(h) profileStart(h)
+#define stopTimer(h)  profileStop(h)
+
+/* ---- yamlOutput.h ---- */
+extern FILE* yamlFile;
+void yamlBegin(void);
+void yamlEnd(void);
+void yamlAppInfo(FILE* file);
+void printSeparator(FILE* file);
+
+/* ---- embedding API (Python/ctypes, tests, bench): a thin layer over the functions above ---- */
+SimFlat* comdCreate(int argc, char** argv);              /* parse the reference CLI, initSimulation */
+SimFlat* comdCreateHostOnly(int argc, char** argv);      /* parse + initSimulationHost (CPU tests) */
+const HostAtoms* comdHostAtoms(SimFlat* s);              /* the host mirror, without touching the device */
+int      comdSimBoxFromTuple(SimFlat* s, int ix, int iy, int iz);
+int      comdSimBoxFromCoord(SimFlat* s, const double r[3]);
+int      comdFaceCells(SimFlat* s, int kind, int face, int* list);
+void     comdNeighborRanks(SimFlat* s, int nbr[6], int coord[3]);
+void     comdGridInfo(SimFlat* s, int out[6]);            /* gridSize[3], nLocalBoxes, nTotalBoxes, maxAtoms */
+int      comdMain(int argc, char** argv);                /* the reference's main(): CoMD.c:86-187 */
+void     comdDestroy(SimFlat* s);
+void     comdGetEnergy(SimFlat* s, double out[3]);       /* ePotential, eKinetic, nGlobal */
+int      comdNumGlobal(SimFlat* s);
+int      comdNumLocalSlots(SimFlat* s);                  /* nTotalBoxes * maxAtoms */
+/* copy device state to the host mirror and return pointers into it (valid until the next call) */
+const HostAtoms* comdFetchAtoms(SimFlat* s);
+/* per-atom arrays of this rank's local atoms keyed by gid: which 0 r,1 p,2 f (3 doubles) / 3 e, 4 rhobar, 5 dfEmbed (1 double).
+ * `out` must be zero-initialised by the caller when ranks are to be summed. */
+void     comdGatherByGid(SimFlat* s, int which, double* out);
+/* overwrite r or p of local atoms from a by-gid array (which 0 / 1), then upload */
+void     comdScatterByGid(SimFlat* s, int which, const double* in);
+
+#endif

@@ -1,0 +1,159 @@
+/* eam_potential.c -- EAM potential plugin: funcfl table reader (eam.c:802-872), interpolation tables with the
+ * reference's padding rule (:496-519) and host evaluation (:557-579), report (:421-431), and the three-pass force
+ * choreography with the dfEmbed halo exchange in the middle (eamForceGpu, eam.c:196-264). */
+#include "comd_host.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+static int eamForce(SimFlat* s);
+static void eamPrint(FILE* file, BasePotential* pot);
+static void eamDestroy(BasePotential** pot);
+
+static InterpolationObject* initInterpolationObject(int n, real_t x0, real_t dx, const real_t* data)
+{
+   InterpolationObject* t = (InterpolationObject*)calloc(1, sizeof(InterpolationObject));
+   real_t* raw = (real_t*)calloc((size_t)n + 3, sizeof(real_t));
+   t->values = raw + 1;
+   t->n = n; t->invDx = 1.0 / dx; t->x0 = x0; t->invDxXx0 = x0 * t->invDx;
+   for (int i = 0; i < n; ++i) t->values[i] = data[i];
+   t->values[-1] = t->values[0];
+   t->values[n + 1] = t->values[n] = t->values[n - 1];
+   return t;
+}
+
+static void destroyInterpolationObject(InterpolationObject** a)
+{
+   if (!a || !*a) return;
+   if ((*a)->values) free((*a)->values - 1);
+   free(*a);
+   *a = NULL;
+}
+
+void interpolate(InterpolationObject* table, real_t r, real_t* f, real_t* df)
+{
+   const real_t* tt = table->values;
+   if (r < table->x0) r = table->x0;
+   r = (r - table->x0) * table->invDx;
+   int ii = (int)floor(r);
+   if (ii > table->n) { ii = table->n; r = table->n / table->invDx; }
+   r = r - floor(r);
+   real_t g1 = tt[ii + 1] - tt[ii - 1];
+   real_t g2 = tt[ii + 2] - tt[ii];
+   *f = tt[ii] + 0.5 * r * (g1 + r * (tt[ii + 1] + tt[ii - 1] - 2.0 * tt[ii]));
+   *df = 0.5 * (g1 + r * (g2 - g1)) * table->invDx;
+}
+
+static void fileNotFound(const char* callSite, const char* filename)
+{
+   fprintf(screenOut, "%s: Can't open file %s.  Fatal Error.\n", callSite, filename);
+   exit(-1);
+}
+
+/* funcfl: line 1 comment (element first), line 2 "Z mass lat lattice", line 3 "nRho dRho nR dR cutoff", then F(rho),
+ * Z(r) (converted to phi = Z^2/r in eV, phi[0] extrapolated) and rho(r). */
+static void eamReadFuncfl(EamPotential* pot, const char* dir, const char* potName)
+{
+   char tmp[4096];
+   snprintf(tmp, sizeof tmp, "%s/%s", dir, potName);
+   FILE* fp = fopen(tmp, "r");
+   if (!fp) fileNotFound("eamReadFuncfl", tmp);
+   char name[16] = "";
+   if (!fgets(tmp, sizeof tmp, fp)) fileNotFound("eamReadFuncfl", potName);
+   sscanf(tmp, "%15s", name);
+   strncpy(pot->name, name, 2); pot->name[2] = '\0';
+   int nAtomic; double mass, lat; char latticeType[8];
+   if (!fgets(tmp, sizeof tmp, fp)) fileNotFound("eamReadFuncfl", potName);
+   sscanf(tmp, "%d %le %le %7s", &nAtomic, &mass, &lat, latticeType);
+   pot->atomicNo = nAtomic; pot->lat = lat; pot->mass = mass * amuToInternalMass;
+   strcpy(pot->latticeType, latticeType);
+   int nRho, nR; double dRho, dR, cutoff;
+   if (!fgets(tmp, sizeof tmp, fp)) fileNotFound("eamReadFuncfl", potName);
+   sscanf(tmp, "%d %le %d %le %le", &nRho, &dRho, &nR, &dR, &cutoff);
+   pot->cutoff = cutoff;
+   const real_t x0 = 0.0;
+   int bufSize = nRho > nR ? nRho : nR;
+   real_t* buf = (real_t*)malloc((size_t)bufSize * sizeof(real_t));
+   for (int i = 0; i < nRho; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadFuncfl(F)", potName);
+   pot->f = initInterpolationObject(nRho, x0, dRho, buf);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadFuncfl(Z)", potName);
+   for (int i = 1; i < nR; ++i) {
+      real_t r = x0 + i * dR;
+      buf[i] *= buf[i] / r;
+      buf[i] *= hartreeToEv * bohrToAngs;
+   }
+   buf[0] = buf[1] + (buf[1] - buf[2]);
+   pot->phi = initInterpolationObject(nR, x0, dR, buf);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadFuncfl(rho)", potName);
+   pot->rho = initInterpolationObject(nR, x0, dR, buf);
+   free(buf);
+   fclose(fp);
+}
+
+BasePotential* initEamPot(const char* dir, const char* file, const char* type)
+{
+   EamPotential* pot = (EamPotential*)calloc(1, sizeof(EamPotential));
+   pot->force = eamForce;
+   pot->print = eamPrint;
+   pot->destroy = eamDestroy;
+   /* every rank reads the (36 kB) file itself; the reference reads on rank 0 and broadcasts (eam.c:160-171) */
+   if (strcmp(type, "funcfl") == 0) eamReadFuncfl(pot, dir, file);
+   else {
+      fprintf(screenOut, "initEamPot: Potential type %s not supported. Fatal Error.\n", type);   /* setfl: SURVEY 8f */
+      exit(-1);
+   }
+   return (BasePotential*)pot;
+}
+
+static void eamPrint(FILE* file, BasePotential* pot)
+{
+   EamPotential* e = (EamPotential*)pot;
+   fprintf(file, "  Potential type  : EAM\n");
+   fprintf(file, "  Species name    : %s\n", e->name);
+   fprintf(file, "  Atomic number   : %d\n", e->atomicNo);
+   fprintf(file, "  Mass            : %lg amu\n", e->mass / amuToInternalMass);
+   fprintf(file, "  Lattice type    : %s\n", e->latticeType);
+   fprintf(file, "  Lattice spacing : %lg Angstroms\n", e->lat);
+   fprintf(file, "  Cutoff          : %lg Angstroms\n", e->cutoff);
+}
+
+static void eamDestroy(BasePotential** pPot)
+{
+   if (!pPot || !*pPot) return;
+   EamPotential* pot = (EamPotential*)*pPot;
+   destroyInterpolationObject(&pot->phi);
+   destroyInterpolationObject(&pot->rho);
+   destroyInterpolationObject(&pot->f);
+   if (pot->forceExchange) destroyHaloExchange(&pot->forceExchange);
+   free(pot);
+   *pPot = NULL;
+}
+
+static int eamForce(SimFlat* s)
+{
+   EamPotential* pot = (EamPotential*)s->pot;
+   SimGpu* g = &s->gpu;
+   if (s->gpuAsync) {
+      /* passes 1-2 of the interior cells were launched on interior_stream by redistributeAtoms (timestep.c:257-265) */
+      eamForce1GpuAsync(g, s->n_boundary_cells, g->boundary_cells, s->method, g->boundary_stream, s->spline);
+      eamForce2GpuAsync(g, s->n_boundary_cells, g->boundary_cells, s->method, g->boundary_stream, s->spline);
+      comdStreamSynchronize(g->boundary_stream);       /* boundary dfEmbed must exist before it is packed */
+      comdStreamSynchronize(g->interior_stream);       /* pass 3 of interior cells reads dfEmbed of ring-2 boundary cells */
+      eamForce3GpuAsync(g, g->n_interior_cells, g->interior_cells, s->method, g->interior_stream, s->spline);
+   } else {
+      eamForce1Gpu(g, s->method, s->spline);
+      if (!s->gpuProfile) eamForce2Gpu(g, s->method, s->spline);
+   }
+   if (!s->gpuProfile) {
+      startTimer(eamHaloTimer);
+      haloExchange(pot->forceExchange, s);
+      stopTimer(eamHaloTimer);
+      if (s->gpuAsync) {
+         eamForce3GpuAsync(g, s->n_boundary_cells, g->boundary_cells, s->method, g->boundary_stream, s->spline);
+         comdDeviceSynchronize();
+      } else {
+         eamForce3Gpu(g, s->method, s->spline);
+      }
+   }
+   return 0;
+}

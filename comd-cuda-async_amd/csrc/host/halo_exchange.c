@@ -1,0 +1,254 @@
+/* halo_exchange.c -- six-face halo exchange, three sequential axis phases (x, y, z), two messages per phase.
+ *
+ * Same protocol as the reference (haloExchange.c:8-29, exchangeData :1493-1522): per axis pack the minus and plus
+ * faces, exchange both, then unpack minus and plus -- the order that keeps migrating atoms from being duplicated.
+ * Same cell lists (mkAtomCellList :1543-1567, mkForceSend/RecvCellList :1712-1801), same periodic shifts (:316-323),
+ * same HaloExchange {loadBuffer, unloadBuffer, destroy} plugin shape (haloExchange.h:84-104).
+ *
+ * What differs: messages never leave the device.  loadBuffer runs the pack kernels into a device buffer, the
+ * transport moves device memory (RCCL send/recv over xGMI between ranks; nothing at all when a rank is its own
+ * periodic neighbour), unloadBuffer runs the unpack kernels.  The reference stages every message through pinned
+ * host memory and blocks on six count read-backs per exchange (haloExchange.c:1632-1633, gpu_kernels.cu:534-535).
+ * The whole GPUDirect-Async / libmp machinery of haloExchange.c:498-1366 has no counterpart by design.
+ */
+#include "comd_host.h"
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXI(a, b) ((a) > (b) ? (a) : (b))
+
+static HaloExchange* initHaloExchangeBase(Domain* domain)
+{
+   HaloExchange* hh = (HaloExchange*)calloc(1, sizeof(HaloExchange));
+   hh->nbrRank[HALO_X_MINUS] = processorNum(domain, -1,  0,  0);
+   hh->nbrRank[HALO_X_PLUS]  = processorNum(domain, +1,  0,  0);
+   hh->nbrRank[HALO_Y_MINUS] = processorNum(domain,  0, -1,  0);
+   hh->nbrRank[HALO_Y_PLUS]  = processorNum(domain,  0, +1,  0);
+   hh->nbrRank[HALO_Z_MINUS] = processorNum(domain,  0,  0, -1);
+   hh->nbrRank[HALO_Z_PLUS]  = processorNum(domain,  0,  0, +1);
+   return hh;
+}
+
+static int* cellBlock(LinkCell* boxes, const int lo[3], const int hi[3], int nCells)
+{
+   int* list = (int*)malloc((size_t)nCells * sizeof(int));
+   int count = 0;
+   for (int ix = lo[0]; ix < hi[0]; ++ix)
+      for (int iy = lo[1]; iy < hi[1]; ++iy)
+         for (int iz = lo[2]; iz < hi[2]; ++iz)
+            list[count++] = getBoxFromTuple(boxes, ix, iy, iz);
+   if (count != nCells) { fprintf(stderr, "halo cell list: built %d cells, expected %d\n", count, nCells); exit(-1); }
+   return list;
+}
+
+/* atoms: the halo plane and the first local plane of the face, over the full (halo-inclusive) extent of the other
+ * two axes, so that data received on earlier axes is forwarded to edge and corner neighbours */
+int* mkAtomCellList(LinkCell* boxes, enum HaloFaceOrder iFace, int nCells)
+{
+   int lo[3] = { -1, -1, -1 }, hi[3] = { boxes->gridSize[0] + 1, boxes->gridSize[1] + 1, boxes->gridSize[2] + 1 };
+   const int axis = iFace / 2;
+   if (iFace & 1) lo[axis] = hi[axis] - 2; else hi[axis] = lo[axis] + 2;
+   return cellBlock(boxes, lo, hi, nCells);
+}
+
+static void forceBlock(LinkCell* boxes, int face, int recv, int lo[3], int hi[3])
+{
+   const int axis = face / 2;
+   for (int a = 0; a < 3; ++a) {
+      if (a < axis) { lo[a] = -1; hi[a] = boxes->gridSize[a] + 1; }    /* axes already exchanged: their halos ride along */
+      else          { lo[a] = 0;  hi[a] = boxes->gridSize[a]; }
+   }
+   const int g = boxes->gridSize[axis];
+   if (!recv) { if (face & 1) { lo[axis] = g - 1; hi[axis] = g; } else { lo[axis] = 0; hi[axis] = 1; } }
+   else       { if (face & 1) { lo[axis] = g; hi[axis] = g + 1; } else { lo[axis] = -1; hi[axis] = 0; } }
+}
+
+int* mkForceSendCellList(LinkCell* boxes, int face, int nCells)
+{
+   int lo[3], hi[3]; forceBlock(boxes, face, 0, lo, hi);
+   return cellBlock(boxes, lo, hi, nCells);
+}
+
+int* mkForceRecvCellList(LinkCell* boxes, int face, int nCells)
+{
+   int lo[3], hi[3]; forceBlock(boxes, face, 1, lo, hi);
+   return cellBlock(boxes, lo, hi, nCells);
+}
+
+static int* uploadInts(const int* h, int n)
+{
+   int* d = (int*)comdDeviceMalloc((long)n * sizeof(int));
+   comdMemcpyHtoD(d, h, (long)n * sizeof(int));
+   return d;
+}
+
+/* ---- atom exchange plugin ---------------------------------------------------------------------------- */
+static int loadAtomsBuffer(void* vparms, void* data, int face, char* buf)
+{
+   AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
+   SimFlat* sim = (SimFlat*)data;
+   compactCellsGpu(buf, parms->nCells[face], parms->cellListGpu[face], &sim->gpu, parms->d_cellOffsets,
+                   parms->shift[face], parms->capacityAtoms, sim->gpu.boundary_stream);
+   if (getNRanks() == 1) return -1;           /* own periodic image: the count stays on the device */
+   int n = atomMsgCountGpu(&sim->gpu, buf, sim->gpu.boundary_stream);
+   return COMD_ATOM_MSG_HEADER + n * COMD_ATOM_MSG_BYTES_PER_ATOM;
+}
+
+static void unloadAtomsBuffer(void* vparms, void* data, int face, int bufSize, char* buf)
+{
+   AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
+   SimFlat* sim = (SimFlat*)data;
+   (void)face;
+   int nBuf = bufSize < 0 ? -1 : (bufSize - COMD_ATOM_MSG_HEADER) / COMD_ATOM_MSG_BYTES_PER_ATOM;
+   unloadAtomsBufferToGpu(buf, nBuf, parms->capacityAtoms, &sim->gpu, sim->gpu.boundary_stream);
+}
+
+static void destroyAtomsExchange(void* vparms)
+{
+   AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
+   for (int f = 0; f < 6; ++f) { free(parms->cellList[f]); comdDeviceFree(parms->cellListGpu[f]); }
+   comdDeviceFree(parms->d_cellOffsets);
+}
+
+HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice)
+{
+   HaloExchange* hh = initHaloExchangeBase(domain);
+   const int* g = boxes->gridSize;
+   const int size0 = (g[1] + 2) * (g[2] + 2), size1 = (g[0] + 2) * (g[2] + 2), size2 = (g[0] + 2) * (g[1] + 2);
+   const int maxSize = MAXI(size0, MAXI(size1, size2));       /* the reference forgets size0 (haloExchange.c:205-206) */
+   AtomExchangeParms* parms = (AtomExchangeParms*)calloc(1, sizeof(AtomExchangeParms));
+   parms->capacityAtoms = maxSize * 2 * boxes->maxAtoms;
+   hh->bufCapacity = COMD_ATOM_MSG_HEADER + parms->capacityAtoms * COMD_ATOM_MSG_BYTES_PER_ATOM;
+   hh->loadBuffer = loadAtomsBuffer;
+   hh->unloadBuffer = unloadAtomsBuffer;
+   hh->destroy = destroyAtomsExchange;
+   parms->nCells[HALO_X_MINUS] = parms->nCells[HALO_X_PLUS] = 2 * size0;
+   parms->nCells[HALO_Y_MINUS] = parms->nCells[HALO_Y_PLUS] = 2 * size1;
+   parms->nCells[HALO_Z_MINUS] = parms->nCells[HALO_Z_PLUS] = 2 * size2;
+   for (int f = 0; f < 6; ++f) parms->cellList[f] = mkAtomCellList(boxes, (enum HaloFaceOrder)f, parms->nCells[f]);
+   for (int a = 0; a < 3; ++a) {
+      if (domain->procCoord[a] == 0)                       parms->shift[2*a][a]     = +1.0 * domain->globalExtent[a];
+      if (domain->procCoord[a] == domain->procGrid[a] - 1) parms->shift[2*a + 1][a] = -1.0 * domain->globalExtent[a];
+   }
+   hh->type = 0;
+   hh->parms = parms;
+   hh->deviceBuffers = allocDevice;
+   if (allocDevice) {
+      for (int f = 0; f < 6; ++f) parms->cellListGpu[f] = uploadInts(parms->cellList[f], parms->nCells[f]);
+      parms->d_cellOffsets = (int*)comdDeviceMalloc((long)(2 * maxSize + 1) * sizeof(int));
+      hh->sendBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->sendBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
+      hh->recvBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->recvBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
+   }
+   return hh;
+}
+
+/* ---- force (dfEmbed) exchange plugin --------------------------------------------------------------------- */
+static int loadForceBuffer(void* vparms, void* vdata, int face, char* buf)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
+   loadForceBufferFromGpu((real_t*)buf, parms->nCells[face], parms->sendCellsGpu[face], parms->d_cellOffsets, &s->gpu, s->gpu.boundary_stream);
+   if (getNRanks() == 1) return -1;
+   int n = comdReadDeviceInt(parms->d_cellOffsets + parms->nCells[face], s->gpu.boundary_stream);
+   return n * (int)sizeof(real_t);
+}
+
+static void unloadForceBuffer(void* vparms, void* vdata, int face, int bufSize, char* buf)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
+   (void)bufSize;       /* positional: the receive cells hold the same atoms, in gid order, as the sender's send cells */
+   unloadForceBufferToGpu((const real_t*)buf, parms->nCells[face], parms->recvCellsGpu[face], parms->d_cellOffsets, &s->gpu, s->gpu.boundary_stream);
+}
+
+static void destroyForceExchange(void* vparms)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   for (int f = 0; f < 6; ++f) {
+      free(parms->sendCells[f]); free(parms->recvCells[f]);
+      comdDeviceFree(parms->sendCellsGpu[f]); comdDeviceFree(parms->recvCellsGpu[f]);
+   }
+   comdDeviceFree(parms->d_cellOffsets);
+}
+
+HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice)
+{
+   HaloExchange* hh = initHaloExchangeBase(domain);
+   const int* g = boxes->gridSize;
+   const int size0 = g[1] * g[2], size1 = (g[0] + 2) * g[2], size2 = (g[0] + 2) * (g[1] + 2);
+   const int maxSize = MAXI(size0, MAXI(size1, size2));
+   ForceExchangeParms* parms = (ForceExchangeParms*)calloc(1, sizeof(ForceExchangeParms));
+   parms->capacityAtoms = maxSize * boxes->maxAtoms;
+   hh->bufCapacity = parms->capacityAtoms * (int)sizeof(real_t);
+   hh->loadBuffer = loadForceBuffer;
+   hh->unloadBuffer = unloadForceBuffer;
+   hh->destroy = destroyForceExchange;
+   parms->nCells[HALO_X_MINUS] = parms->nCells[HALO_X_PLUS] = size0;
+   parms->nCells[HALO_Y_MINUS] = parms->nCells[HALO_Y_PLUS] = size1;
+   parms->nCells[HALO_Z_MINUS] = parms->nCells[HALO_Z_PLUS] = size2;
+   for (int f = 0; f < 6; ++f) {
+      parms->sendCells[f] = mkForceSendCellList(boxes, f, parms->nCells[f]);
+      parms->recvCells[f] = mkForceRecvCellList(boxes, f, parms->nCells[f]);
+   }
+   hh->type = 1;
+   hh->parms = parms;
+   hh->deviceBuffers = allocDevice;
+   if (allocDevice) {
+      for (int f = 0; f < 6; ++f) {
+         parms->sendCellsGpu[f] = uploadInts(parms->sendCells[f], parms->nCells[f]);
+         parms->recvCellsGpu[f] = uploadInts(parms->recvCells[f], parms->nCells[f]);
+      }
+      parms->d_cellOffsets = (int*)comdDeviceMalloc((long)(maxSize + 1) * sizeof(int));
+      hh->sendBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->sendBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
+      hh->recvBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->recvBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
+   }
+   return hh;
+}
+
+void destroyHaloExchange(HaloExchange** pp)
+{
+   if (!pp || !*pp) return;
+   HaloExchange* hh = *pp;
+   hh->destroy(hh->parms);
+   free(hh->parms);
+   if (hh->deviceBuffers) {
+      comdDeviceFree(hh->sendBufM); comdDeviceFree(hh->sendBufP); comdDeviceFree(hh->recvBufM); comdDeviceFree(hh->recvBufP);
+   }
+   free(hh);
+   *pp = NULL;
+}
+
+/* ---- driver -------------------------------------------------------------------------------------------------- */
+void exchangeData(HaloExchange* hh, void* data, int iAxis)
+{
+   const int faceM = 2 * iAxis, faceP = faceM + 1;
+   int nSendM = hh->loadBuffer(hh->parms, data, faceM, hh->sendBufM);
+   int nSendP = hh->loadBuffer(hh->parms, data, faceP, hh->sendBufP);
+   const int nbrM = hh->nbrRank[faceM], nbrP = hh->nbrRank[faceP];
+
+   if (nbrM == getMyRank() && nbrP == getMyRank()) {
+      /* this rank is its own neighbour along the axis: what it sends through the minus face arrives through its plus
+       * face.  Unpack straight from the send buffers (the reference's comm path has the same shortcut, haloExchange.c:788-853). */
+      hh->unloadBuffer(hh->parms, data, faceM, nSendP, hh->sendBufP);
+      hh->unloadBuffer(hh->parms, data, faceP, nSendM, hh->sendBufM);
+      return;
+   }
+   int nRecvP, nRecvM;
+   if (hh->deviceBuffers) {
+      SimFlat* sim = (SimFlat*)data;
+      nRecvP = sendReceiveDevice(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->bufCapacity, nbrP, sim->gpu.boundary_stream);
+      nRecvM = sendReceiveDevice(hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity, nbrM, sim->gpu.boundary_stream);
+   } else {
+      nRecvP = sendReceiveParallel(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->bufCapacity, nbrP);
+      nRecvM = sendReceiveParallel(hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity, nbrM);
+   }
+   hh->unloadBuffer(hh->parms, data, faceM, nRecvM, hh->recvBufM);
+   hh->unloadBuffer(hh->parms, data, faceP, nRecvP, hh->recvBufP);
+}
+
+void haloExchange(HaloExchange* hh, void* data)
+{
+   startTimer(commHaloTimer);
+   for (int iAxis = 0; iAxis < 3; ++iAxis) exchangeData(hh, data, iAxis);
+   stopTimer(commHaloTimer);
+}

@@ -1,0 +1,79 @@
+/* parallel.c -- rank bookkeeping and the pluggable transport behind the reference's parallel.h API
+ * (parallel.c:24-193: getNRanks/getMyRank/printRank, sendReceiveParallel, addXParallel, maxIntParallel, bcastParallel,
+ * barrierParallel, timestampBarrier).  The reference binds these to MPI; here one process drives one GPU and the
+ * transport is a small vtable: none (single rank), RCCL over xGMI (libcomd_hip's comdComm*), or callbacks supplied
+ * by the embedding program (the CPU tests plug torch.distributed/gloo in). */
+#include "comd_host.h"
+#include <string.h>
+#include <time.h>
+#include <stdlib.h>
+
+static int myRank = 0;
+static int nRanks = 1;
+static CommTransport transport;
+static int haveTransport = 0;
+
+void initParallel(int rank, int n, const CommTransport* t)
+{
+   myRank = rank; nRanks = n;
+   haveTransport = 0;
+   if (t) { transport = *t; haveTransport = 1; }
+   if (nRanks > 1 && !haveTransport) {
+      fprintf(stderr, "initParallel: %d ranks need a transport\n", nRanks);
+      exit(-1);
+   }
+}
+
+void destroyParallel(void) { haveTransport = 0; myRank = 0; nRanks = 1; }
+int getNRanks(void) { return nRanks; }
+int getMyRank(void) { return myRank; }
+int printRank(void) { return myRank == 0; }
+
+void barrierParallel(void) { if (nRanks > 1) transport.barrier(transport.ctx); }
+
+void timestampBarrier(const char* msg)
+{
+   barrierParallel();
+   if (!printRank()) return;
+   time_t t = time(NULL);
+   char* timeString = ctime(&t);
+   timeString[24] = '\0';
+   fprintf(screenOut, "%s: %s\n", timeString, msg);
+   fflush(screenOut);
+}
+
+/* host buffers; single rank: copy to self, as the serial build of the reference does (parallel.c:112-117) */
+int sendReceiveParallel(void* sendBuf, int sendLen, int dest, void* recvBuf, int recvLen, int source)
+{
+   if (nRanks == 1) { (void)dest; (void)source; if (sendLen > recvLen) sendLen = recvLen; memcpy(recvBuf, sendBuf, (size_t)sendLen); return sendLen; }
+   return transport.sendrecv(transport.ctx, sendBuf, sendLen, dest, recvBuf, recvLen, source, 0, NULL);
+}
+
+/* device buffers, ordered on `stream` */
+int sendReceiveDevice(void* sendBuf, int sendLen, int dest, void* recvBuf, int recvLen, int source, comdStream_t stream)
+{
+   if (nRanks == 1) { comdMemcpyDtoDAsync(recvBuf, sendBuf, sendLen, stream); return sendLen; }
+   return transport.sendrecv(transport.ctx, sendBuf, sendLen, dest, recvBuf, recvLen, source, 1, stream);
+}
+
+void addIntParallel(int* sendBuf, int* recvBuf, int count)
+{
+   memmove(recvBuf, sendBuf, (size_t)count * sizeof(int));
+   if (nRanks > 1) transport.allreduce(transport.ctx, recvBuf, count, 0);
+}
+
+void addRealParallel(real_t* sendBuf, real_t* recvBuf, int count)
+{
+   memmove(recvBuf, sendBuf, (size_t)count * sizeof(real_t));
+   if (nRanks > 1) transport.allreduce(transport.ctx, recvBuf, count, 1);
+}
+
+void addDoubleParallel(double* sendBuf, double* recvBuf, int count) { addRealParallel(sendBuf, recvBuf, count); }
+
+void maxIntParallel(int* sendBuf, int* recvBuf, int count)
+{
+   memmove(recvBuf, sendBuf, (size_t)count * sizeof(int));
+   if (nRanks > 1) transport.allreduce(transport.ctx, recvBuf, count, 2);
+}
+
+void bcastParallel(void* buf, int len, int root) { if (nRanks > 1) transport.bcast(transport.ctx, buf, len, root); }

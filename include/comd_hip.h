@@ -1,0 +1,276 @@
+/* comd_hip.h -- C ABI of libcomd_hip.so, the MI355X (gfx950) device library behind CoMD's
+ * pair-force + velocity-Verlet hot path.
+ *
+ * Every entry point replaces one extern "C" launch wrapper of the reference
+ * (e-ago/CoMD-CUDA-Async, src-mpi/gpu_kernels.h:13-92 and src-mpi/gpu_utility.h:55-69); the
+ * comment above each declaration cites the interface it stands in for.  Signatures carry plain
+ * pointers, sizes and PODs only -- no HIP, torch or C++ types -- so a C host (ours, or the
+ * reference's src-mpi C files with the shim of INTEGRATION.md) links against it directly.
+ *
+ * Differences from the reference ABI, all deliberate:
+ *  - MAXATOMS (a -D macro in the reference Makefile:16) is the run-time field SimGpu.maxAtoms.
+ *  - there is no a_list/i_list/b_list indirection (gpu_types.h:115-121): kernels are launched over
+ *    cell slots (cell*maxAtoms + i) and mask by nAtoms[cell].
+ *  - every cell is kept in ascending-gid order on the device, so atom order is a pure function of
+ *    cell membership (the reference sorts boundary/halo cells only, gpu_kernels.cu:1013-1043).
+ *  - entry points that took SimFlat* take SimGpu* (+ explicit scalars): the device library does
+ *    not know the host's simulation struct.
+ *  - streams are opaque `comdStream_t` (a hipStream_t underneath; NULL = the default stream).
+ *  - errors: any HIP failure prints "Rank r, GPU g, Error in file f at line l" + the HIP error
+ *    string to stderr and exit(-1)s, as CUDA_CHECK does (gpu_utility.h:71-90).
+ */
+#ifndef COMD_HIP_H
+#define COMD_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef double real_t;                 /* mytype.h:16 (COMD_DOUBLE build) */
+typedef void*  comdStream_t;
+
+typedef struct vec_t { real_t* x; real_t* y; real_t* z; } vec_t;          /* mytype.h:24-28 */
+
+/* force-kernel variants, defines.h:11-17 (the *_NL and warp_atom values are accepted and mapped
+ * to thread_atom; they are outside the hot-path scope) */
+enum { THREAD_ATOM = 0, THREAD_ATOM_NL = 1, WARP_ATOM = 2, WARP_ATOM_NL = 3, CTA_CELL = 4, CPU_NL = 5 };
+
+/* gpu_types.h:48-58 */
+typedef struct InterpolationObjectGpu {
+   int     n;
+   real_t  x0, xn, invDx, invDxHalf, invDxXx0;
+   real_t* values;                     /* device, n+3 entries, values[0] is the leading pad */
+} InterpolationObjectGpu;
+
+/* gpu_types.h:72-79 */
+typedef struct LjPotentialGpu { real_t cutoff, sigma, epsilon; } LjPotentialGpu;
+
+/* gpu_types.h:81-96 (spline tables: out of scope) */
+typedef struct EamPotentialGpu {
+   real_t cutoff;
+   InterpolationObjectGpu phi, rho, f;
+   real_t* rhobar;                     /* device [nTotalBoxes*maxAtoms] */
+   real_t* dfEmbed;                    /* device [nTotalBoxes*maxAtoms] */
+} EamPotentialGpu;
+
+/* gpu_types.h:98-112 */
+typedef struct LinkCellGpu {
+   int    nLocalBoxes, nTotalBoxes;
+   int    gridSize[3];
+   real_t localMin[3], localMax[3], invBoxSize[3];
+   int*   nAtoms;                      /* device [nTotalBoxes] */
+} LinkCellGpu;
+
+/* gpu_types.h:148-157 */
+typedef struct AtomsGpu {
+   vec_t   r, p, f;                    /* device SoA, [nTotalBoxes*maxAtoms] each */
+   real_t* e;
+   int*    iSpecies;
+   int*    gid;                        /* -1 marks a hole between updateLinkCellsGpu's two phases */
+} AtomsGpu;
+
+/* gpu_types.h:159-190.  Passed by pointer everywhere (the reference passes 856 bytes by value). */
+typedef struct SimGpu {
+   int          maxAtoms;              /* slot capacity of a link cell (Makefile:16 MAXATOMS) */
+   int          deviceId, rank;
+   AtomsGpu     atoms;
+   int*         neighbor_cells;        /* device [nLocalBoxes*27], self first (gpu_utility.c:520-531) */
+   real_t*      species_mass;          /* device [1] */
+   real_t       mass;                  /* host copy of species_mass[0] */
+   LinkCellGpu  boxes;
+   LjPotentialGpu  lj_pot;
+   EamPotentialGpu eam_pot;
+   int          do_eam;
+   /* cell typing for communication overlap, gpu_utility.c:73-163 SetBoundaryCells */
+   int          n_boundary_cells, n_interior_cells, n_boundary1_cells;
+   int*         boundary_cells;        /* device: local cells within two rings of the surface */
+   int*         interior_cells;        /* device: the other local cells */
+   int*         boundary1_cells;       /* device: outermost ring */
+   comdStream_t boundary_stream, interior_stream;
+   /* redistribution scratch (CoMDTypes.h:123-126 flags/tmp_sort) */
+   int*         nAtomsPrev;            /* device [nTotalBoxes]: occupancy snapshot */
+   int*         cellDirty;             /* device [nTotalBoxes]: membership changed, needs compaction + gid sort */
+   int*         status;                /* device [4]: {cell overflow, lost atom, msg overflow, spare} */
+   real_t*      reduceBuf;             /* device: per-block partial sums for computeEnergy */
+   real_t*      pinned;                /* pinned host staging (energies, counts) */
+   int          reduceBlocks;
+} SimGpu;
+
+/* Everything AllocateGpu needs to know about the rank's geometry and potential.
+ * Replaces the SimFlat* argument of gpu_utility.c:165-282 AllocateGpu. */
+typedef struct GpuConfig {
+   int    maxAtoms;
+   int    nLocalBoxes, nTotalBoxes, gridSize[3];
+   real_t localMin[3], localMax[3], boxSize[3];
+   int    do_eam, gpuAsync, rank;
+   real_t mass;
+   real_t ljCutoff, ljSigma, ljEpsilon;
+   real_t eamCutoff;
+   int    nPhi, nRho, nF;                         /* table lengths (n, not n+3) */
+   real_t phiX0, phiInvDx, rhoX0, rhoInvDx, fX0, fInvDx;
+   const real_t *phiValues, *rhoValues, *fValues; /* host, n+3 entries each, element 0 = values[-1] */
+   const int* neighborCells;                      /* host [nLocalBoxes*27] */
+} GpuConfig;
+
+/* Host-side mirror of the slot arrays (CoMDTypes.h Atoms / gpu_utility.c:432-600 staging). */
+typedef struct HostAtoms {
+   int*    nAtoms;                     /* [nTotalBoxes] */
+   int*    gid;  int* iSpecies;        /* [nTotalBoxes*maxAtoms] */
+   real_t *rx, *ry, *rz, *px, *py, *pz, *fx, *fy, *fz, *e;
+} HostAtoms;
+
+/* ---- device management: gpu_utility.h:55-69 --------------------------------------------- */
+/* SetupGpu(int deviceId), gpu_utility.c:32-71: select the device, print its name. Returns the CU count. */
+int  SetupGpu(int deviceId, int rank, int verbose);
+/* number of visible devices (CoMD.c:105 cudaGetDeviceCount); 0 when there is none. Never exits. */
+int  comdDeviceCount(void);
+/* AllocateGpu(SimFlat*, do_eam, skin), gpu_utility.c:165-282 */
+void AllocateGpu(SimGpu* sim, const GpuConfig* cfg);
+/* SetBoundaryCells(SimFlat*, HaloExchange*), gpu_utility.c:73-163: upload the cell-type lists built by the host */
+void SetBoundaryCells(SimGpu* sim, int nBoundary, const int* boundary, int nInterior, const int* interior,
+                      int nBoundary1, const int* boundary1);
+/* CopyDataToGpu(SimFlat*, do_eam), gpu_utility.c:432-600 */
+void CopyDataToGpu(SimGpu* sim, const HostAtoms* host);
+/* GetDataFromGpu(SimFlat*), gpu_utility.c:617-653 (f and e included) */
+void GetDataFromGpu(SimGpu* sim, HostAtoms* host);
+/* updateNAtomsCpu(SimFlat*), gpu_utility.c: refresh the host copy of nAtoms (CoMD.c:445-452 reads it) */
+void updateNAtomsCpu(SimGpu* sim, int* nAtomsHost);
+/* DestroyGpu(SimFlat*), gpu_utility.c:284-347 */
+void DestroyGpu(SimGpu* sim);
+/* emptyHaloCellsGpu(SimFlat*), gpu_utility.c: zero the halo cells' occupancy */
+void emptyHaloCellsGpu(SimGpu* sim, comdStream_t stream);
+/* cudaDeviceSynchronize / cudaStreamSynchronize as the host code uses them (eam.c:209, 256) */
+void comdDeviceSynchronize(void);
+void comdStreamSynchronize(comdStream_t stream);
+/* device allocation helpers for buffers the host owns (haloExchange.c:228-246, CoMDTypes.h:125-126) */
+void* comdDeviceMalloc(long bytes);
+void  comdDeviceFree(void* p);
+void* comdHostMallocPinned(long bytes);
+void  comdHostFreePinned(void* p);
+void  comdMemcpyHtoD(void* dst, const void* src, long bytes);
+void  comdMemcpyDtoH(void* dst, const void* src, long bytes);
+void  comdMemcpyDtoDAsync(void* dst, const void* src, long bytes, comdStream_t stream);
+/* check SimGpu.status; prints and exit(-1)s on cell overflow / lost atoms (DEBUG asserts of gpu_redistribute.h:145-154) */
+void comdCheckStatus(SimGpu* sim, const char* where);
+
+/* ---- force: gpu_kernels.h:13-24 ------------------------------------------------------------ */
+/* ljForceGpu(SimGpu*, interpolation, num_cells, cells_list, plcutoff, method), gpu_kernels.cu:69-122.
+ * cells_list (device) == NULL means cells 0..num_cells-1.  interpolation/plcutoff are accepted for
+ * signature parity and must be 0 (table-LJ and pairlists are out of scope): non-zero exits. */
+void ljForceGpu(SimGpu* sim, int interpolation, int num_cells, int* cells_list, real_t plcutoff, int method);
+void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream);
+/* eamForce{1,2,3}Gpu(SimGpu, method, spline), gpu_kernels.cu:154-249; spline must be 0 */
+void eamForce1Gpu(SimGpu* sim, int method, int spline);
+void eamForce2Gpu(SimGpu* sim, int method, int spline);
+void eamForce3Gpu(SimGpu* sim, int method, int spline);
+/* eamForce{1,2,3}GpuAsync(SimGpu, AtomListGpu, num_cells, cells_list, method, stream, spline);
+ * the AtomListGpu argument has no counterpart here (no atom lists) */
+void eamForce1GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline);
+void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline);
+void eamForce3GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline);
+/* updateNeighborsGpu[Async], gpu_kernels.cu:251-279: the reference materialises 27*MAXATOMS neighbour
+ * offsets per cell for its cta_cell/warp_atom EAM kernels; ours gather from the cell table directly,
+ * so these are no-ops kept for link compatibility. */
+void updateNeighborsGpu(SimGpu* sim, int* temp);
+void updateNeighborsGpuAsync(SimGpu* sim, int* temp, int nCells, int* cellList, comdStream_t stream);
+
+/* ---- integrator + energy: gpu_kernels.h:79-83 --------------------------------------------- */
+/* advanceVelocityGpu(SimGpu, dt), gpu_kernels.cu:326-334 */
+void advanceVelocityGpu(SimGpu* sim, real_t dt);
+/* advancePositionGpu(SimGpu*, dt), gpu_kernels.cu:336-349 */
+void advancePositionGpu(SimGpu* sim, real_t dt);
+/* computeEnergy(SimFlat*, real_t eLocal[2]), gpu_kernels.cu:1045-1059: {sum e, sum p^2/2m} of local atoms.
+ * Deterministic two-stage reduction (the reference uses fp64 atomics). Blocks until the result is on the host. */
+void computeEnergy(SimGpu* sim, real_t* eLocal);
+
+/* ---- redistribute: gpu_kernels.h:84-86 ------------------------------------------------------ */
+/* updateLinkCellsGpu(SimFlat*), gpu_kernels.cu:469-504: empty the halo cells, move every local atom whose
+ * coordinates left its cell, then compact + gid-sort the cells that changed. */
+void updateLinkCellsGpu(SimGpu* sim, comdStream_t stream);
+/* buildAtomListGpu(SimFlat*, stream), gpu_kernels.cu:553-570: nothing to rebuild here; kept as the hook
+ * where the reference rebuilds a_list after the halo exchange.  No-op. */
+void buildAtomListGpu(SimGpu* sim, comdStream_t stream);
+/* sortAtomsGpu(SimFlat*, stream), gpu_kernels.cu:1013-1043: compact + gid-sort every cell whose membership
+ * changed since the last sort (halo cells, cells that received migrants). */
+void sortAtomsGpu(SimGpu* sim, comdStream_t stream);
+
+/* ---- halo pack / unpack: gpu_kernels.h:26-72 ------------------------------------------------ */
+/* Atom message, device or host: 16-byte header {int n; int pad[3]} followed by the reference's SoA wire
+ * format (gpu_kernels.cu:506-517 getAtomMsgSoAPtr): int gid[n]; int type[n]; double rx[n],ry[n],rz[n],px[n],py[n],pz[n]. */
+#define COMD_ATOM_MSG_HEADER 16
+#define COMD_ATOM_MSG_BYTES_PER_ATOM 56
+typedef struct AtomMsgSoA {            /* haloExchange.h AtomMsgSoA */
+   int *gid, *type; real_t *rx, *ry, *rz, *px, *py, *pz;
+} AtomMsgSoA;
+/* getAtomMsgSoAPtr(buffer, &msg, n), gpu_kernels.cu:506-517; buffer points at the header */
+void getAtomMsgSoAPtr(char* buffer, AtomMsgSoA* atomMsg, int n);
+/* compactCellsGpu(work_d, nCells, d_cellList, sim, d_cellOffsets, d_workScan, shift, stream), gpu_kernels.cu:519-551:
+ * exclusive-scan the occupancies of the listed cells and gather their atoms (positions shifted by `shift`) into
+ * the message at work_d, in cell-list order.  d_cellOffsets needs nCells+1 ints.  Nothing is copied to the host and
+ * the call does not block; the count is in the message header.  capacityAtoms bounds the message. */
+void compactCellsGpu(char* work_d, int nCells, int* d_cellList, SimGpu* sim, int* d_cellOffsets,
+                     const real_t shift[3], int capacityAtoms, comdStream_t stream);
+/* blocking read of a device message's atom count (the reference returns it from compactCellsGpu, :534-535) */
+int  atomMsgCountGpu(SimGpu* sim, const char* msg_d, comdStream_t stream);
+/* unloadAtomsBufferToGpu(buf, nBuf, SimFlat*, gpu_buf, stream), gpu_kernels.cu:572-617: bin every atom of the device
+ * message into its link cell by coordinate (getBoxFromCoord), appending to the cell and marking it for sorting.
+ * nBuf < 0: take the count from the message header on the device; maxAtomsInMsg bounds the launch. */
+void unloadAtomsBufferToGpu(const char* msg_d, int nBuf, int maxAtomsInMsg, SimGpu* sim, comdStream_t stream);
+/* loadForceBufferFromGpu(buf, &nbuf, nCells, cellList, natoms_buf, partial_sums, SimFlat*, gpu_buf, stream), :619-640:
+ * gather dfEmbed of the listed cells, in list order, into gpu_buf (real_t[]); d_cellOffsets needs nCells+1 ints.
+ * Does not block; the count ends up in d_cellOffsets[nCells]. */
+void loadForceBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream);
+/* unloadForceBufferToGpu(buf, nBuf, nCells, cellList, natoms_buf, partial_sums, SimFlat*, gpu_buf, stream), :642-660 */
+void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream);
+/* blocking read of one device int (message counts for the multi-rank transport) */
+int  comdReadDeviceInt(const int* d_ptr, comdStream_t stream);
+
+
+/* ---- inter-rank transport: replaces comm.h:40-74 (libmp/GPUDirect-Async) and parallel.h (MPI) --------------
+ * A small vtable the host's parallel layer calls.  libcomd_hip.so provides the RCCL-over-xGMI implementation
+ * (comdCommInitRank / comdCommInitFromEnv); an embedding program may supply its own (the CPU tests plug
+ * torch.distributed/gloo in through callbacks). */
+typedef struct CommTransportSt {
+   void* ctx;
+   /* paired exchange of BYTES (parallel.c:100-118 sendReceiveParallel).  device != 0: the buffers are device memory
+    * and the transfer is ordered on `stream`.  Returns the number of bytes received (<= recvCap). */
+   int  (*sendrecv)(void* ctx, const void* sendBuf, int sendLen, int dest, void* recvBuf, int recvCap, int source,
+                    int device, comdStream_t stream);
+   void (*allreduce)(void* ctx, void* buf, int count, int dtype /* 0 int sum, 1 double sum, 2 int max */);
+   void (*bcast)(void* ctx, void* buf, int len, int root);
+   void (*barrier)(void* ctx);
+} CommTransport;
+#define COMD_UNIQUE_ID_BYTES 128
+/* rank 0: create the RCCL unique id (ncclGetUniqueId); the caller distributes the 128 bytes to every rank */
+int  comdCommGetUniqueId(char* id128);
+/* every rank, after SetupGpu: join the communicator and fill `out` with the RCCL transport */
+int  comdCommInitRank(const char* id128, int rank, int nRanks, CommTransport* out);
+/* standalone launcher path: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT from the environment, id through a file */
+int  comdCommInitFromEnv(CommTransport* out, int* rank, int* nRanks, int* localRank);
+void comdCommFinalize(void);
+
+/* ---- neighbour-list / pairlist bookkeeping: gpu_kernels.h:25, 73-78, 87-92 ------------------
+ * Out of the hot-path scope.  Exported so the reference's host objects link;
+ * "always rebuild" semantics, no state. */
+void emptyNeighborListGpu(SimGpu* sim, int boundaryFlag);
+int  neighborListUpdateRequiredGpu(SimGpu* sim);
+int  pairlistUpdateRequiredGpu(SimGpu* sim);
+void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag);
+
+/* ---- device-side timing for bench.py -------------------------------------------------------- */
+/* HIP-event pair on a stream: comdEventCreate/Record/ElapsedMs.  Used to time kernels on the stream they
+ * run on (torch.cuda.Event only sees torch's own stream). */
+void*  comdEventCreate(void);
+void   comdEventRecord(void* ev, comdStream_t stream);
+float  comdEventElapsedMs(void* start, void* stop);   /* synchronises on `stop` */
+void   comdEventDestroy(void* ev);
+/* accumulated device time of the force kernels since the last reset: the library brackets every force launch
+ * with events when timing is enabled (off by default; adds two event records per launch). */
+void   comdForceTimingEnable(int on);
+void   comdForceTimingReset(void);
+double comdForceTimingTotalMs(int* nLaunches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

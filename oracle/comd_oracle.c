@@ -128,6 +128,9 @@ static int boxFromCoord(const Rank* k, const double r[3])
    int t[3];
    for (int a = 0; a < 3; ++a) {
       t[a] = (int)floor((r[a] - k->lmin[a]) * k->binv[a]);
+      if (t[a] < -1 || t[a] > k->g[a]) {     /* moved more than one cell in a step: outside the halo, lost */
+         fprintf(stderr, "oracle: an atom left the halo region (axis %d, cell %d of %d)\n", a, t[a], k->g[a]); abort();
+      }
       if (r[a] < k->lmax[a]) { if (t[a] == k->g[a]) t[a] = k->g[a] - 1; }
       else t[a] = k->g[a];
    }

@@ -1,0 +1,131 @@
+"""Host-side logic of the product (no GPU): lattice, momenta, link-cell numbering, halo cell lists, CLI, C-ABI exports.
+Everything is compared bit-for-bit with the oracle, which is itself pinned to the reference (test_oracle_golden.py)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module", autouse=True)
+def single_rank(pkg):
+    pkg.init_parallel(0, 1, None)
+
+
+def _by_gid(cells, n_local):
+    out = {}
+    for b in range(n_local):
+        for i in range(cells["nAtoms"][b]):
+            out[int(cells["gid"][b, i])] = tuple(cells[k][b, i] for k in ("rx", "ry", "rz", "px", "py", "pz"))
+    return out
+
+
+@pytest.mark.parametrize("eam,n", [(0, 10), (1, 6), (1, 9)])
+def test_initial_state_matches_oracle_bit_for_bit(pkg, orc, eam, n):
+    """FCC sites, gids, cell assignment, Maxwell-Boltzmann momenta (lcg61/gasdev streams, COM removal, rescale)."""
+    with pkg.Simulation(["-x", n, "-y", n, "-z", n] + (["-e"] if eam else []), host_only=True) as s:
+        o = orc.Oracle(n, eam=eam, cap=s.max_atoms)
+        assert s.grid == o.rank_grid(0)[0]
+        c, oc = s.cells(), o.rank_cells(0)
+        nl = s.n_local_boxes
+        assert np.array_equal(c["nAtoms"][:nl], oc["nAtoms"][:nl])
+        for b in range(nl):
+            k = c["nAtoms"][b]
+            assert np.array_equal(c["gid"][b, :k], oc["gid"][b, :k])
+            for name in ("rx", "ry", "rz", "px", "py", "pz"):
+                assert np.array_equal(c[name][b, :k], oc[name][b, :k]), name
+
+
+def test_displaced_state_matches_oracle_by_gid(pkg, orc):
+    with pkg.Simulation(["-x", 8, "-y", 8, "-z", 8, "-r", 0.3, "-e"], host_only=True) as s:
+        o = orc.Oracle(8, eam=1, delta=0.3, cap=s.max_atoms)
+        assert _by_gid(s.cells(), s.n_local_boxes) == _by_gid(o.rank_cells(0), s.n_local_boxes)
+
+
+def test_cell_numbering_and_tie_rules(pkg, orc):
+    """getBoxFromTuple for every tuple incl. halo, getBoxFromCoord incl. positions exactly on faces and just outside."""
+    with pkg.Simulation(["-x", 9, "-y", 7, "-z", 8, "-e"], host_only=True) as s:
+        o = orc.Oracle((9, 7, 8), eam=1, cap=s.max_atoms)
+        gx, gy, gz = s.grid
+        seen = set()
+        for ix in range(-1, gx + 1):
+            for iy in range(-1, gy + 1):
+                for iz in range(-1, gz + 1):
+                    b = s.box_from_tuple(ix, iy, iz)
+                    assert b == o.L.oracle_box_from_tuple(o.ptr, 0, ix, iy, iz)
+                    seen.add(b)
+        assert seen == set(range(s.n_total_boxes)), "numbering is a bijection onto [0, nTotalBoxes)"
+        lat = 3.615
+        ext = np.array([9, 7, 8]) * lat
+        rng = np.random.default_rng(7)
+        box = ext / np.array(s.grid)
+        pts = list(rng.uniform(-0.99, 1.0, (300, 3)) * 0 + (-0.99 * box + rng.uniform(0.0, 1.0, (300, 3)) * (ext + 1.98 * box)))
+        eps = np.finfo(float).eps
+        for a in range(3):
+            for v in (0.0, ext[a], np.nextafter(ext[a], 0), np.nextafter(0.0, -1), ext[a] * (1 - eps), -1e-9, ext[a] + 1e-9):
+                p = ext * 0.5
+                p[a] = v
+                pts.append(p.copy())
+        for p in pts:
+            arr = np.ascontiguousarray(p, dtype=np.float64)
+            assert s.box_from_coord(p) == o.L.oracle_box_from_coord(o.ptr, 0, arr.ctypes.data), p
+
+
+@pytest.mark.parametrize("eam,n", [(0, 14), (1, 7)])
+def test_halo_cell_lists(pkg, orc, eam, n):
+    with pkg.Simulation(["-x", n, "-y", n, "-z", n] + (["-e"] if eam else []), host_only=True) as s:
+        o = orc.Oracle(n, eam=eam, cap=s.max_atoms)
+        for face in range(6):
+            for kind in range(3):
+                assert np.array_equal(s.face_cells(kind, face), o.face_cells(0, kind, face))
+
+
+def test_capacity_rule(pkg):
+    """LJ capacity is a multiple of 64 (waves never straddle cells); EAM capacity is a power of two."""
+    with pkg.Simulation(["-x", 20, "-y", 20, "-z", 20], host_only=True) as s:
+        assert s.max_atoms % 64 == 0 and s.max_atoms >= s.cells()["nAtoms"].max() * 1.1
+    with pkg.Simulation(["-x", 20, "-y", 20, "-z", 20, "-e"], host_only=True) as s:
+        assert s.max_atoms & (s.max_atoms - 1) == 0 and s.max_atoms >= s.cells()["nAtoms"].max() * 1.1
+    with pkg.Simulation(["-x", 10, "-y", 10, "-z", 10, "--maxAtoms", 192], host_only=True) as s:
+        assert s.max_atoms == 192
+
+
+def test_abi_exports_every_declared_symbol(pkg):
+    """libcomd_hip.so exports every function include/comd_hip.h declares (load only; no device calls)."""
+    header = open(os.path.join(ROOT, "include", "comd_hip.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    names = set(re.findall(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", header, flags=re.M))
+    names -= {"sendrecv", "allreduce", "bcast", "barrier"}
+    assert {"ljForceGpu", "eamForce1Gpu", "eamForce2Gpu", "eamForce3Gpu", "advanceVelocityGpu", "advancePositionGpu",
+            "computeEnergy", "updateLinkCellsGpu", "buildAtomListGpu", "sortAtomsGpu", "compactCellsGpu",
+            "unloadAtomsBufferToGpu", "loadForceBufferFromGpu", "unloadForceBufferToGpu", "getAtomMsgSoAPtr",
+            "AllocateGpu", "CopyDataToGpu", "GetDataFromGpu", "DestroyGpu", "SetBoundaryCells"} <= names
+    lib = pkg.lib_hip()
+    missing = [n for n in sorted(names) if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_device_means_loud_failure(pkg):
+    """Without a GPU the product refuses to run: no CPU fallback."""
+    if pkg.lib_hip().comdDeviceCount() > 0:
+        pytest.skip("a device is visible")
+    with pytest.raises(RuntimeError):
+        pkg.setup_gpu(0, 0)
+    exe = os.path.join(ROOT, "comd-cuda-async_amd", "csrc", "comd-hip")
+    proc = subprocess.run([exe, "-x", "10", "-y", "10", "-z", "10"], capture_output=True, text=True, env={k: v for k, v in os.environ.items() if k != "WORLD_SIZE"})
+    assert proc.returncode != 0 and "no HIP device" in proc.stderr
+
+
+def test_product_never_links_the_oracle():
+    """The oracle is test infrastructure: nothing under the product package may mention it."""
+    pkg_dir = os.path.join(ROOT, "comd-cuda-async_amd")
+    for dirpath, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith((".c", ".h", ".hip", ".py", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "liboracle" not in text and "comd_oracle" not in text and "oracle_binding" not in text, f
+    out = subprocess.run(["ldd", os.path.join(pkg_dir, "csrc", "libcomd_host.so")], capture_output=True, text=True).stdout
+    assert "oracle" not in out

@@ -1,0 +1,122 @@
+"""The oracle (oracle/comd_oracle.c) against every known answer the reference holds for this path.
+
+Pins: CoMD.c:896-900 (EAM cohesive energy), the step-0 row of the reference's captured K20 log, and the values
+SURVEY.md section 8c recorded from the unmodified reference CPU path (tests/golden/reference_values.json).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_values.json")))
+TOL = G["tolerances"]
+S = G["survey_recorded"]
+
+
+def per_atom(o):
+    ep, ek = o.energy()
+    return (ep + ek) / o.n_global, ep / o.n_global, ek / o.n_global
+
+
+def test_eam_cohesive_energy_repo_native(orc):
+    """Perfect FCC Cu lattice, Adams EAM: -3.538079224691 eV/atom (CoMD.c:898)."""
+    o = orc.Oracle(6, eam=1, temperature=0.0)
+    _, u, k = per_atom(o)
+    assert k == 0.0
+    assert abs(u - G["repo_native"]["eam_adams_cohesive_energy"]["value"]) < TOL["energy_per_atom_step0"]
+
+
+def test_eam_step0_row_of_k20_log(orc):
+    """Step-0 row of out16_80_3.txt: U and K per atom do not depend on the lattice size for a perfect lattice at exactly 600 K."""
+    ref = G["repo_native"]["eam_80_step0_gpu_log"]
+    o = orc.Oracle(20, eam=1)
+    e, u, k = per_atom(o)
+    assert abs(u - ref["U"]) < TOL["energy_per_atom_step0"]
+    assert abs(k - ref["K"]) < 1e-11      # exact rescale to T = 600 K: K = 1.5 kB T
+    assert abs(e - ref["E"]) < TOL["energy_per_atom_step0"]
+
+
+@pytest.mark.parametrize("case,procs", [("eam_20", (1, 1, 1)), ("eam_20_8ranks", (2, 2, 2)), ("lj_20", (1, 1, 1)), ("lj_20_8ranks", (2, 2, 2))])
+def test_energy_trace_20_cubed(orc, case, procs):
+    """Step-0 energies and E_tot at step 10 for 20^3, on 1 and on 2x2x2 virtual ranks (decomposition independence)."""
+    ref = S[case]
+    o = orc.Oracle(ref["nx"], procs, eam=ref["eam"])
+    e, u, k = per_atom(o)
+    if "U" in ref["step0"]:
+        assert abs(u - ref["step0"]["U"]) < TOL["energy_per_atom_step0"]
+    if "E" in ref["step0"]:
+        assert abs(e - ref["step0"]["E"]) < TOL["energy_per_atom_step0"]
+    o.step(10)
+    e, _, _ = per_atom(o)
+    assert abs(e - ref["E_at"]["10"]) < TOL["energy_per_atom_trace"]
+
+
+def test_eam_trace_to_step_30(orc):
+    """Cell- and list-independent trace recorded with three different skins: E_tot at 10 / 20 / 30."""
+    ref = S["eam_20_skin"]["E_at"]
+    o = orc.Oracle(20, eam=1)
+    for step in (10, 20, 30):
+        o.step(10)
+        assert abs(per_atom(o)[0] - ref[str(step)]) < TOL["energy_per_atom_trace"]
+
+
+@pytest.mark.parametrize("case", ["eam_6_delta", "lj_8_delta"])
+def test_per_atom_forces_with_displacement(orc, case):
+    """-r 0.1 cases: energy per atom, sum and max of |f|, f(gid 0) and (EAM) the displaced position of gid 0."""
+    ref = S[case]
+    o = orc.Oracle(ref["nx"], eam=ref["eam"], delta=ref["delta"])
+    _, u, _ = per_atom(o)
+    assert abs(u - ref["U_per_atom"]) < 1e-13 * abs(ref["U_per_atom"]) * 10
+    f = o.gather(orc.F)
+    norms = np.linalg.norm(f, axis=1)
+    assert abs(norms.sum() - ref["sum_norm_f"]) < 1e-9 * ref["sum_norm_f"]      # recorded to 13 digits
+    assert abs(norms.max() - ref["max_norm_f"]) < 1e-11
+    assert np.abs(f[0] - np.array(ref["f_gid0"])).max() < TOL["force_rel_to_max"] * ref["max_norm_f"]
+    if "r_gid0" in ref:
+        r = o.gather(orc.R)
+        assert np.abs(r[0] - np.array(ref["r_gid0"])).max() < 1e-15
+
+
+def test_decomposition_independence_per_atom(orc):
+    """Forces of the same displaced lattice on 1 rank and on 2x2x1 virtual ranks agree atom by atom."""
+    a = orc.Oracle(12, (1, 1, 1), eam=1, delta=0.2)
+    b = orc.Oracle(12, (2, 2, 1), eam=1, delta=0.2)
+    fa, fb = a.gather(orc.F), b.gather(orc.F)
+    assert np.abs(fa - fb).max() < 1e-12 * np.abs(fa).max()
+    assert np.abs(a.gather(orc.U) - b.gather(orc.U)).max() < 1e-12
+
+
+def _owner_cells(o):
+    owner = np.zeros(o.n_global, dtype=np.int64)
+    for rank in range(o.n_ranks):
+        c = o.rank_cells(rank)
+        _, nl, _ = o.rank_grid(rank)
+        for b in range(nl):
+            owner[c["gid"][b, :c["nAtoms"][b]]] = rank * 100000 + b
+    return owner
+
+
+def test_migration_across_ranks_conserves_atoms(orc):
+    """A rigid translation by ~0.4 cell pushes ~half the atoms into another cell and many across rank and periodic
+    boundaries in one redistribution; every gid must survive exactly once, cells stay in gid order, and forces and
+    energy are translation invariant."""
+    o = orc.Oracle(12, (2, 1, 2), eam=1, delta=0.05, cap=64)
+    owner0 = _owner_cells(o)
+    f0, u0 = o.gather(orc.F), o.energy()[0]
+    o.scatter(orc.R, o.gather(orc.R) + np.array([2.1, -1.9, 2.3]))
+    o.redistribute()
+    o.compute_force()
+    o.kinetic_energy()
+    assert (_owner_cells(o) != owner0).sum() > o.n_global // 4, "the test must actually exercise migration"
+    seen = np.zeros(o.n_global, dtype=np.int64)
+    for rank in range(o.n_ranks):
+        c = o.rank_cells(rank)
+        _, nl, _ = o.rank_grid(rank)
+        for b in range(nl):
+            g = c["gid"][b, :c["nAtoms"][b]]
+            assert np.all(np.diff(g) > 0), "cells are kept in ascending gid order"
+            seen[g] += 1
+    assert np.all(seen == 1)
+    assert abs(o.energy()[0] - u0) < 1e-11 * abs(u0)
+    assert np.abs(o.gather(orc.F) - f0).max() < 1e-10 * np.abs(f0).max()
