@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""bench.py -- atom-updates/s of the CoMD hot path (force + velocity-Verlet + redistribute + halo) on MI355X.
+
+    python bench.py                       # 1 GPU, LJ Cu 80^3 (BASELINE.json configs[1]), thread_atom, fp64
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W     # weak scaling: 80^3 atoms per GPU
+
+A "step" is one full time step of timestep() (timestep.c:48-100).  The timed region is exactly K steps bracketed by a
+barrier + device synchronisation on both sides; the maximum over ranks is reported.  `value` is the whole-job rate:
+nGlobal * K / seconds.  Atoms are resident in HBM when the timed region starts (they are generated on the host once,
+uploaded by CopyDataToGpu, and never leave the device).
+
+Extra objects on the JSON line:
+  roofline     : the dominant kernel (the LJ or EAM force kernel) against the 8 TB/s HBM roof, from HIP events recorded
+                 on the launch stream around every force launch of the timed region (comdForceTiming*).
+                 Algorithmic bytes per atom: LJ force 56 B, EAM force (3 passes) 176 B.
+  cpu_baseline : the CPU restatement (oracle/, kind "port") timed on this host's cores on a bounded sample of the same
+                 workload (same potential, same density, fewer atoms and steps), rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as ge  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0
+FORCE_BYTES = {"lj": 56.0, "eam": 176.0}        # algorithmic bytes per atom per force evaluation
+STEP_BYTES = {"lj": 276.0, "eam": 396.0}        # ... per full time step (force + 2 half kicks + drift)
+GRIDS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--pot", choices=["lj", "eam"], default="lj")
+    ap.add_argument("--method", choices=["thread_atom", "cta_cell"], default=None)
+    ap.add_argument("--nx", type=int, default=80, help="unit cells per GPU along each axis")
+    ap.add_argument("--async-halo", type=int, default=None, help="-a flag: overlap interior force with the halo exchange")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def cpu_baseline(pot, seconds):
+    """Time the oracle on this host: 20^3 cells of the same lattice/potential (BASELINE configs[0] for LJ)."""
+    orc = ge.load_oracle()
+    n = 20
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    orc.lib().oracle_set_threads(min(cores, 16))        # the GPU box gives one GPU a 16-core share
+    t0 = time.time()
+    o = orc.Oracle(n, eam=1 if pot == "eam" else 0)
+    o.step(2)
+    per_step = max((time.time() - t0) / 3.0, 1e-4)
+    steps = max(5, min(200, int(seconds / per_step)))
+    lib = orc.lib()
+    before = lib.oracle_loop_seconds(o.ptr)
+    o.step(steps)
+    loop = lib.oracle_loop_seconds(o.ptr) - before
+    rate = o.n_global * steps / loop
+    return {"value": rate, "unit": "atom-updates/s", "cores": int(lib.oracle_threads()), "kind": "port",
+            "sample": f"{pot.upper()} Cu {n}^3 FCC ({o.n_global} atoms), {steps} steps, oracle/comd_oracle.c (27-cell stencil form, OpenMP), {loop:.1f} s"}
+
+
+def main():
+    a = parse()
+    method = a.method or ("thread_atom" if a.pot == "lj" else "cta_cell")
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run --nproc-per-node N")
+        a.gpus = world
+    if a.gpus not in GRIDS:
+        sys.exit("supported GPU counts: 1, 2, 4, 8")
+    px, py, pz = GRIDS[a.gpus]
+    use_async = a.async_halo if a.async_halo is not None else (1 if a.gpus > 1 else 0)
+
+    pkg = ge.load_package()
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("gloo")                     # control plane only; halo data moves over RCCL
+    pkg.setup_gpu(local_rank, rank, verbose=(rank == 0))
+    if world > 1:
+        ids = [pkg.rccl_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(ids, src=0)
+        transport = pkg.rccl_transport(rank, world, ids[0])
+        pkg.init_parallel(rank, world, transport)
+    else:
+        pkg.init_parallel(0, 1, None)
+
+    args = ["-x", a.nx * px, "-y", a.nx * py, "-z", a.nx * pz, "-i", px, "-j", py, "-k", pz,
+            "-m", method, "-a", use_async] + (["-e"] if a.pot == "eam" else [])
+    sim = pkg.Simulation(args)
+    hip = pkg.lib_hip()
+
+    def sync_all():
+        hip.comdDeviceSynchronize()
+        if dist is not None:
+            dist.barrier()
+        hip.comdDeviceSynchronize()
+
+    sim.step(a.warmup)
+    sync_all()
+    hip.comdForceTimingEnable(1)
+    hip.comdForceTimingReset()
+    t0 = time.perf_counter()
+    sim.step(a.steps)
+    hip.comdDeviceSynchronize()
+    if dist is not None:
+        dist.barrier()
+    hip.comdDeviceSynchronize()
+    elapsed = time.perf_counter() - t0
+    import ctypes
+    n_launch = ctypes.c_int(0)
+    force_ms = hip.comdForceTimingTotalMs(ctypes.byref(n_launch))
+    hip.comdForceTimingEnable(0)
+
+    if dist is not None:
+        import torch
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    ep, ek, n_global = sim.energy()
+    sim.sum_atoms()
+    assert sim.energy()[2] == n_global, "atoms were lost"
+
+    if rank == 0:
+        n_local = n_global / a.gpus
+        value = n_global * a.steps / elapsed
+        force_per_step_ms = force_ms / a.steps                 # all force launches of one step on rank 0
+        achieved = FORCE_BYTES[a.pot] * n_local / (force_per_step_ms * 1e-3) / 1e9 if force_ms > 0 else None
+        out = {
+            "metric": "atom_updates_per_sec", "value": value, "unit": "atom-updates/s",
+            "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.pot.upper()} Cu FCC {a.nx}^3 unit cells per GPU ({int(n_local)} atoms/GPU, {n_global} total), "
+                                   f"{method} kernel, fp64, T=600 K, dt=1 fs",
+                       "decomposition": f"{px}x{py}x{pz}", "halo_overlap": bool(use_async), "cell_capacity": sim.max_atoms},
+            "per_gpu_value": value / a.gpus,
+            "energy_per_atom_eV": (ep + ek) / n_global,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "kernel": ("LJ_Force_" if a.pot == "lj" else "EAM_Force_") + method,
+                         "kernel_ms_per_step": force_per_step_ms, "launches_timed": int(n_launch.value),
+                         "algorithmic_bytes_per_atom": FORCE_BYTES[a.pot],
+                         "whole_step_achieved_GBs": STEP_BYTES[a.pot] * value / a.gpus / 1e9,
+                         "note": "fp64 ALU-bound stencil: ~4000 (LJ) / ~283 (EAM) candidate pairs per atom against 56 / 176 algorithmic bytes (SURVEY.md 8d)"},
+        }
+        if a.gpus == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a.pot, a.cpu_seconds)
+        print(json.dumps(out))
+    sim.close()
+    if dist is not None:
+        dist.barrier()
+        pkg.lib_hip().comdCommFinalize()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -760,6 +760,15 @@ double oracle_lattice(const OracleSim* s)     { return s->lat; }
 double oracle_loop_seconds(const OracleSim* s){ return s->loopSeconds; }
 int    oracle_rank_cell_cap(const OracleSim* s) { return s->cap; }
 
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+   if (n > 0) omp_set_num_threads(n);
+#else
+   (void)n;
+#endif
+}
+
 int oracle_threads(void)
 {
 #ifdef _OPENMP

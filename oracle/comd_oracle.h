@@ -85,6 +85,7 @@ int      oracle_eam_table(const OracleSim* s, int table, int* n, double* x0, dou
 double oracle_loop_seconds(const OracleSim* s);
 /* number of OpenMP threads the force loops use (1 when built without -fopenmp) */
 int    oracle_threads(void);
+void   oracle_set_threads(int n);
 
 #ifdef __cplusplus
 }

@@ -55,6 +55,7 @@ def lib():
     L.oracle_eam_interpolate.argtypes = [vp, ci, cd, ctypes.POINTER(cd), ctypes.POINTER(cd)]
     L.oracle_eam_table.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(cd), ctypes.POINTER(cd), vp]
     L.oracle_threads.restype = ci
+    L.oracle_set_threads.argtypes = [ci]
     _lib = L
     return L
 

@@ -1,0 +1,198 @@
+"""Parity of the HIP path (through the C ABI) with the oracle on identical inputs -- run with `-m gpu` on an MI355X.
+
+Tolerances (fp64): per-atom force |df| <= 1e-11 * max|f|, per-atom energy 1e-11 eV, energy per atom along a trace
+2e-12 eV/atom against the reference's recorded values (tests/golden/reference_values.json, "tolerances").
+Index work (cell membership, gid order, halo images, positions after the periodic shift) must be bit-exact.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_values.json")))
+TOL = G["tolerances"]
+S = G["survey_recorded"]
+METHODS = ["thread_atom", "cta_cell"]
+
+
+def _args(n, eam=0, delta=0.0, method="thread_atom", extra=()):
+    nx, ny, nz = (n, n, n) if isinstance(n, int) else n
+    return ["-x", nx, "-y", ny, "-z", nz, "-r", delta, "-m", method] + (["-e"] if eam else []) + list(extra)
+
+
+def _per_atom(sim):
+    ep, ek, n = sim.energy()
+    return (ep + ek) / n, ep / n, ek / n
+
+
+# ---------------------------------------------------------------- forces and energies of one evaluation
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("eam,n,delta", [(0, 10, 0.0), (0, 10, 0.1), (0, (10, 14, 11), 0.2), (1, 8, 0.0), (1, 8, 0.1), (1, (7, 9, 12), 0.3)])
+def test_forces_match_oracle(gpu, orc, method, eam, n, delta):
+    with gpu.Simulation(_args(n, eam, delta, method)) as sim:
+        o = orc.Oracle(n, eam=eam, delta=delta, cap=max(sim.max_atoms, 64))
+        f, e = sim.gather(2), sim.gather(3)
+        fo, eo = o.gather(orc.F), o.gather(orc.U)
+        assert np.abs(f - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
+        assert np.abs(e - eo).max() <= TOL["per_atom_energy_abs"]
+        ep, ek, ng = sim.energy()
+        op, ok = o.energy()
+        assert abs(ep - op) / ng < TOL["energy_per_atom_step0"] and abs(ek - ok) / ng < 1e-13
+        if eam:
+            assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < 1e-12
+            assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < 1e-12
+
+
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("case", ["eam_6_delta", "lj_8_delta"])
+def test_reference_recorded_forces(gpu, case, method):
+    """The -r 0.1 known answers recorded from the unmodified reference."""
+    ref = S[case]
+    if case == "lj_8_delta" and method == "cta_cell":
+        pytest.skip("8^3 LJ has 256-atom cells: 27 of them exceed the cta_cell kernel's LDS staging (6400 atoms)")
+    with gpu.Simulation(_args(ref["nx"], ref["eam"], ref["delta"], method)) as sim:
+        _, u, _ = _per_atom(sim)
+        assert abs(u - ref["U_per_atom"]) < 1e-12
+        f = sim.gather(2)
+        norms = np.linalg.norm(f, axis=1)
+        assert abs(norms.sum() - ref["sum_norm_f"]) < 1e-9 * ref["sum_norm_f"]
+        assert abs(norms.max() - ref["max_norm_f"]) < 1e-11
+        assert np.abs(f[0] - np.array(ref["f_gid0"])).max() < TOL["force_rel_to_max"] * ref["max_norm_f"]
+
+
+# ---------------------------------------------------------------- energy traces
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("case", ["lj_20", "eam_20"])
+def test_energy_trace_matches_reference(gpu, case, method):
+    ref = S[case]
+    with gpu.Simulation(_args(ref["nx"], ref["eam"], 0.0, method)) as sim:
+        e, u, _ = _per_atom(sim)
+        assert abs(u - ref["step0"]["U"]) < TOL["energy_per_atom_step0"]
+        assert abs(e - ref["step0"]["E"]) < TOL["energy_per_atom_step0"]
+        done = 0
+        for step in (10, 50, 100):
+            sim.step(step - done)
+            done = step
+            assert abs(_per_atom(sim)[0] - ref["E_at"][str(step)]) < TOL["energy_per_atom_trace"], step
+        e, u, k = _per_atom(sim)
+        assert abs(u - ref["step100"]["U"]) < 5e-12
+        sim.sum_atoms()
+        assert sim.energy()[2] == 4 * ref["nx"] ** 3
+
+
+def test_eam_cohesive_energy(gpu):
+    """CoMD.c:898: perfect Adams-EAM lattice, -3.538079224691 eV/atom."""
+    with gpu.Simulation(_args(10, 1, 0.0, "cta_cell", ["-T", 0])) as sim:
+        assert abs(_per_atom(sim)[1] - G["repo_native"]["eam_adams_cohesive_energy"]["value"]) < TOL["energy_per_atom_step0"]
+
+
+@pytest.mark.parametrize("eam,n", [(0, 12), (1, 9)])
+def test_trajectory_tracks_oracle(gpu, orc, eam, n):
+    """25 steps from a displaced lattice: positions, momenta and forces stay together atom by atom."""
+    with gpu.Simulation(_args(n, eam, 0.15)) as sim:
+        o = orc.Oracle(n, eam=eam, delta=0.15, cap=max(sim.max_atoms, 64))
+        sim.step(25)
+        o.step(25)
+        assert np.abs(sim.gather(0) - o.gather(orc.R)).max() < 1e-11
+        assert np.abs(sim.gather(1) - o.gather(orc.P)).max() < 1e-10 * np.abs(o.gather(orc.P)).max()
+        assert np.abs(sim.gather(2) - o.gather(orc.F)).max() < 1e-9 * np.abs(o.gather(orc.F)).max()
+
+
+# ---------------------------------------------------------------- index work: bit-exact
+def _assert_cells_equal(c, oc, n_total):
+    assert np.array_equal(c["nAtoms"], oc["nAtoms"])
+    for b in range(n_total):
+        k = c["nAtoms"][b]
+        assert np.array_equal(c["gid"][b, :k], oc["gid"][b, :k]), b
+        for name in ("rx", "ry", "rz", "px", "py", "pz"):
+            assert np.array_equal(c[name][b, :k], oc[name][b, :k]), (b, name)
+
+
+@pytest.mark.parametrize("eam,n,shift", [(1, 8, (2.1, -1.9, 2.3)), (1, (7, 9, 8), (-2.4, 2.2, -0.3)), (0, 10, (5.0, -4.5, 3.9))])
+def test_redistribution_is_bit_exact(gpu, orc, eam, n, shift):
+    """Rigid translation by a fraction of a cell: ~half the atoms change cell, many wrap periodically.  Afterwards every
+    cell -- local and halo -- must hold exactly the oracle's atoms, in gid order, with bit-identical r (incl. the
+    periodic shift added by the halo pack) and p; forces and energy are translation invariant."""
+    # the device appends movers before it squeezes the holes they leave, so a cell transiently holds old + incoming
+    # atoms; with 3/4 of all atoms moving at once (never the case in MD) that needs 2x the usual head-room
+    extra = ["--maxAtoms", 64 if eam else 384]
+    with gpu.Simulation(_args(n, eam, 0.05, extra=extra)) as sim:
+        o = orc.Oracle(n, eam=eam, delta=0.05, cap=sim.max_atoms)
+        _assert_cells_equal(sim.cells(), o.rank_cells(0), sim.n_total_boxes)      # initial redistribute
+        f0 = sim.gather(2)
+        u0 = sim.energy()[0]
+        r = sim.gather(0)
+        assert np.array_equal(r, o.gather(orc.R))
+        sim.scatter(0, r + np.array(shift))
+        o.scatter(orc.R, r + np.array(shift))
+        sim.redistribute(); sim.compute_force(); sim.kinetic_energy()
+        o.redistribute()
+        c, oc = sim.cells(), o.rank_cells(0)
+        _assert_cells_equal(c, oc, sim.n_total_boxes)
+        moved = sum(int(c["nAtoms"][b]) for b in range(sim.n_local_boxes))
+        assert moved == sim.n_global
+        assert abs(sim.energy()[0] - u0) < 1e-11 * abs(u0)
+        assert np.abs(sim.gather(2) - f0).max() < 1e-10 * np.abs(f0).max()
+
+
+def test_halo_cells_are_periodic_images(gpu):
+    """Every halo atom is a copy of a local atom displaced by a lattice vector of the box; gid order inside cells."""
+    n = 8
+    with gpu.Simulation(_args(n, 1, 0.1)) as sim:
+        c = sim.cells()
+        ext = n * 3.615
+        local = {}
+        for b in range(sim.n_local_boxes):
+            for i in range(c["nAtoms"][b]):
+                local[int(c["gid"][b, i])] = (c["rx"][b, i], c["ry"][b, i], c["rz"][b, i])
+        assert len(local) == sim.n_global
+        n_halo = 0
+        for b in range(sim.n_local_boxes, sim.n_total_boxes):
+            g = c["gid"][b, :c["nAtoms"][b]]
+            assert np.all(np.diff(g) > 0)
+            for i, gid in enumerate(g):
+                d = np.array([c["rx"][b, i], c["ry"][b, i], c["rz"][b, i]]) - np.array(local[int(gid)])
+                k = np.rint(d / ext)
+                assert np.abs(d - k * ext).max() < 1e-12 and np.abs(k).max() == 1
+                n_halo += 1
+        assert n_halo > sim.n_global          # 8^3 EAM: the halo shell holds more images than there are atoms
+
+
+# ---------------------------------------------------------------- properties at BASELINE size
+@pytest.mark.parametrize("eam,method,steps", [(0, "thread_atom", 10), (1, "cta_cell", 20)])
+def test_full_size_properties(gpu, eam, method, steps):
+    """80^3 (2,048,000 atoms), BASELINE configs 2 and 3: the oracle is too slow here, so check what the physics guarantees:
+    step-0 energy equals the recorded reference value, total energy is conserved, total momentum stays zero,
+    forces sum to zero, no atom is lost, cells stay sorted."""
+    ref = S["lj_80_8ranks" if not eam else "eam_80_8ranks"]
+    with gpu.Simulation(_args(80, eam, 0.0, method)) as sim:
+        e0, u0, k0 = _per_atom(sim)
+        if eam:
+            # the reference's own captured GPU log of this exact problem (step-0 row, repo-native pin) ...
+            log = G["repo_native"]["eam_80_step0_gpu_log"]
+            assert abs(u0 - log["U"]) < 2e-12 and abs(k0 - log["K"]) < 2e-12 and abs(e0 - log["E"]) < 2e-12
+            # ... and its CPU path, whose single running sum over 2 M atoms carries ~1e-10 of round-off
+            assert abs(u0 - ref["step0"]["U"]) < 1e-10
+        else:
+            assert abs(u0 - ref["step0"]["U"]) < TOL["energy_per_atom_step0"]
+        sim.step(steps)
+        e1 = _per_atom(sim)[0]
+        key = str(steps)
+        if key in ref["E_at"]:
+            assert abs(e1 - ref["E_at"][key]) < TOL["energy_per_atom_trace"] * 2
+        assert abs(e1 - e0) < 5e-6 * abs(e0)
+        sim.sum_atoms()
+        assert sim.energy()[2] == 4 * 80 ** 3
+        c = sim.cells()
+        nl = sim.n_local_boxes
+        mask = np.arange(sim.max_atoms)[None, :] < c["nAtoms"][:nl, None]
+        for name in ("px", "py", "pz", "fx", "fy", "fz"):
+            tot = c[name][:nl][mask].sum()
+            scale = np.abs(c[name][:nl][mask]).sum()
+            assert abs(tot) < 1e-11 * scale, name
+        g = np.where(mask, c["gid"][:nl], np.iinfo(np.int32).max)
+        assert np.all(np.diff(g.astype(np.int64), axis=1) >= 0)
+        assert np.array_equal(np.sort(c["gid"][:nl][mask]), np.arange(4 * 80 ** 3))
