@@ -90,6 +90,8 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("gloo")                     # control plane only; halo data moves over RCCL
+    if "COMD_FORCE_DEVICE" in os.environ:               # debugging aid: several ranks on one GPU
+        local_rank = int(os.environ["COMD_FORCE_DEVICE"])
     pkg.setup_gpu(local_rank, rank, verbose=(rank == 0))
     if world > 1:
         ids = [pkg.rccl_unique_id() if rank == 0 else None]

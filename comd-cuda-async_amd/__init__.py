@@ -32,6 +32,10 @@ BCAST_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int
 BARRIER_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
 
 
+LOAD_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
+UNLOAD_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+
+
 class CommTransport(ctypes.Structure):
     """include/comd_hip.h CommTransport"""
     _fields_ = [("ctx", ctypes.c_void_p), ("sendrecv", SENDRECV_FN), ("allreduce", ALLREDUCE_FN),
@@ -69,6 +73,9 @@ def lib_hip():
         lib.comdEventElapsedMs.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.comdEventElapsedMs.restype = ctypes.c_float
         lib.comdEventDestroy.argtypes = [ctypes.c_void_p]
+        lib.comdStreamSynchronize.argtypes = [ctypes.c_void_p]
+        lib.comdMemcpyDtoH.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
+        lib.comdMemcpyHtoD.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_long]
         lib._typed = True
     return lib
 
@@ -97,6 +104,9 @@ def lib_host():
         lib.comdSimBoxFromCoord.argtypes = [vp, c_double_p]
         lib.comdFaceCells.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
         lib.comdNeighborRanks.argtypes = [vp, c_int_p, c_int_p]
+        lib.comdHaloExchangeHost.argtypes = [vp, LOAD_FN, UNLOAD_FN]
+        lib.comdFaceShift.argtypes = [vp, ctypes.c_int, c_double_p]
+        lib.comdPutAtomInBox.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p]
         lib.comdGatherByGid.argtypes = [vp, ctypes.c_int, c_double_p]
         lib.comdScatterByGid.argtypes = [vp, ctypes.c_int, c_double_p]
         lib.timestep.argtypes = [vp, ctypes.c_int, ctypes.c_double]
@@ -258,3 +268,79 @@ def run_main(args):
     """The reference's main() (CoMD.c:86-187): full stdout report + YAML file."""
     argc, argv = _argv(list(args))
     return lib_host().comdMain(argc, argv)
+
+
+class GlooTransport:
+    """CommTransport backed by torch.distributed (gloo): host staging, any number of processes per GPU.
+
+    The production transport is RCCL over xGMI (rccl_transport).  This one exists so that the multi-rank host logic
+    can be exercised where RCCL cannot run: on CPU-only machines (host buffers, the CPU test-suite) and with several
+    ranks sharing ONE GPU (device buffers are staged through pinned-less host copies).  It plays the role the
+    reference's plain-MPI path does (haloExchange.c:1493-1522 + parallel.c:100-118).
+    """
+
+    def __init__(self, dist):
+        import numpy as np
+        import torch
+        self.dist, self.torch, self.np = dist, torch, np
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.hip = None
+        self._keep = (SENDRECV_FN(self._sendrecv), ALLREDUCE_FN(self._allreduce), BCAST_FN(self._bcast), BARRIER_FN(self._barrier))
+        self.struct = CommTransport(None, *self._keep)
+
+    def _exchange(self, send_bytes, dest, source, recv_cap):
+        torch, dist = self.torch, self.dist
+        n_send = torch.tensor([len(send_bytes)], dtype=torch.int64)
+        n_recv = torch.zeros(1, dtype=torch.int64)
+        if dest == self.rank and source == self.rank:
+            return bytes(send_bytes)
+        reqs = [dist.isend(n_send, dest, tag=1), dist.irecv(n_recv, source, tag=1)]
+        for r in reqs:
+            r.wait()
+        n = int(n_recv[0])
+        if n > recv_cap:
+            raise RuntimeError(f"incoming message of {n} bytes exceeds the {recv_cap}-byte buffer")
+        out = torch.empty(max(n, 1), dtype=torch.uint8)
+        payload = torch.frombuffer(bytearray(send_bytes), dtype=torch.uint8) if len(send_bytes) else torch.zeros(1, dtype=torch.uint8)
+        reqs = []
+        if len(send_bytes):
+            reqs.append(dist.isend(payload, dest, tag=2))
+        if n:
+            reqs.append(dist.irecv(out, source, tag=2))
+        for r in reqs:
+            r.wait()
+        return out.numpy()[:n].tobytes()
+
+    def _sendrecv(self, ctx, send_buf, send_len, dest, recv_buf, recv_cap, source, device, stream):
+        if device:
+            hip = self.hip or lib_hip()
+            hip.comdStreamSynchronize(ctypes.c_void_p(stream))
+            staging = ctypes.create_string_buffer(max(send_len, 1))
+            if send_len:
+                hip.comdMemcpyDtoH(staging, ctypes.c_void_p(send_buf), ctypes.c_long(send_len))
+            data = self._exchange(staging.raw[:send_len], dest, source, recv_cap)
+            if data:
+                up = ctypes.create_string_buffer(data, len(data))
+                hip.comdMemcpyHtoD(ctypes.c_void_p(recv_buf), up, ctypes.c_long(len(data)))
+        else:
+            data = self._exchange(ctypes.string_at(send_buf, send_len), dest, source, recv_cap)
+            ctypes.memmove(recv_buf, data, len(data))
+        return len(data)
+
+    def _allreduce(self, ctx, buf, count, dtype):
+        np, torch, dist = self.np, self.torch, self.dist
+        ctype = ctypes.c_double if dtype == 1 else ctypes.c_int
+        arr = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctype)), shape=(count,))
+        t = torch.from_numpy(arr.copy())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX if dtype == 2 else dist.ReduceOp.SUM)
+        arr[:] = t.numpy()
+
+    def _bcast(self, ctx, buf, length, root):
+        np, torch = self.np, self.torch
+        arr = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctypes.c_uint8)), shape=(length,))
+        t = torch.from_numpy(arr.copy())
+        self.dist.broadcast(t, src=root)
+        arr[:] = t.numpy()
+
+    def _barrier(self, ctx):
+        self.dist.barrier()

@@ -250,6 +250,9 @@ int      comdSimBoxFromTuple(SimFlat* s, int ix, int iy, int iz);
 int      comdSimBoxFromCoord(SimFlat* s, const double r[3]);
 int      comdFaceCells(SimFlat* s, int kind, int face, int* list);
 void     comdNeighborRanks(SimFlat* s, int nbr[6], int coord[3]);
+void     comdHaloExchangeHost(SimFlat* s, int (*load)(void*, void*, int, char*), void (*unload)(void*, void*, int, int, char*));
+void     comdFaceShift(SimFlat* s, int face, double out[3]);
+int      comdPutAtomInBox(SimFlat* s, int gid, int type, const double r[3], const double p[3]);
 void     comdGridInfo(SimFlat* s, int out[6]);            /* gridSize[3], nLocalBoxes, nTotalBoxes, maxAtoms */
 int      comdMain(int argc, char** argv);                /* the reference's main(): CoMD.c:86-187 */
 void     comdDestroy(SimFlat* s);

@@ -404,6 +404,33 @@ void comdNeighborRanks(SimFlat* s, int nbr[6], int coord[3])
    for (int a = 0; a < 3; ++a) coord[a] = s->domain->procCoord[a];
 }
 
+/* Drive the atom halo exchange (exchangeData x 3 axes) over HOST buffers with caller-supplied loadBuffer/unloadBuffer.
+ * The production plugins pack/unpack on the device; this entry lets a CPU-only program exercise the routing, ordering
+ * and transport logic with its own pack/unpack (the multi-process CPU tests do, over torch.distributed/gloo). */
+void comdHaloExchangeHost(SimFlat* s, int (*load)(void*, void*, int, char*), void (*unload)(void*, void*, int, int, char*))
+{
+   HaloExchange* hh = initAtomHaloExchange(s->domain, s->boxes, 0);
+   hh->bufCapacity = ((AtomExchangeParms*)hh->parms)->capacityAtoms * 64 + 64;
+   hh->sendBufM = (char*)malloc((size_t)hh->bufCapacity); hh->sendBufP = (char*)malloc((size_t)hh->bufCapacity);
+   hh->recvBufM = (char*)malloc((size_t)hh->bufCapacity); hh->recvBufP = (char*)malloc((size_t)hh->bufCapacity);
+   hh->loadBuffer = load; hh->unloadBuffer = unload;
+   haloExchange(hh, s);
+   free(hh->sendBufM); free(hh->sendBufP); free(hh->recvBufM); free(hh->recvBufP);
+   destroyHaloExchange(&hh);
+}
+
+void comdFaceShift(SimFlat* s, int face, double out[3])
+{
+   HaloExchange* hh = initAtomHaloExchange(s->domain, s->boxes, 0);
+   for (int a = 0; a < 3; ++a) out[a] = ((AtomExchangeParms*)hh->parms)->shift[face][a];
+   destroyHaloExchange(&hh);
+}
+
+int comdPutAtomInBox(SimFlat* s, int gid, int type, const double r[3], const double p[3])
+{
+   return putAtomInBox(s->boxes, s->atoms, gid, type, r[0], r[1], r[2], p[0], p[1], p[2]);
+}
+
 void comdDestroy(SimFlat* s) { destroySimulation(&s); }
 
 void comdGetEnergy(SimFlat* s, double out[3]) { out[0] = s->ePotential; out[1] = s->eKinetic; out[2] = (double)s->atoms->nGlobal; }

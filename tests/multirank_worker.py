@@ -1,0 +1,158 @@
+"""Worker for the multi-process tests.  Launched by tests/test_multirank.py through torch.multiprocessing / subprocess:
+
+    python multirank_worker.py <mode> <rank> <world> <port> <px> <py> <pz> <eam> <n> [method] [async]
+
+mode "host": CPU only.  Product host logic on `world` real processes over torch.distributed/gloo: decomposition, lattice,
+             momenta (allreduce), the atom halo-exchange driver with a numpy pack/unpack -- compared with the oracle's
+             virtual ranks, bit for bit.
+mode "gpu" : every rank drives the HIP path on cuda:0 (ranks share the one GPU of the test box); halo messages are device
+             buffers moved by the host-staged gloo transport.  Energies and per-atom forces are compared with the oracle.
+"""
+import ctypes
+import os
+import struct
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import __graft_entry__ as ge  # noqa: E402
+
+REC = struct.Struct("<ii6d")      # the reference's AtomMsg (haloExchange.h:32-38)
+
+
+def host_mode(pkg, orc, transport, rank, world, grid, eam, n):
+    args = ["-x", n, "-y", n, "-z", n, "-i", grid[0], "-j", grid[1], "-k", grid[2], "-r", 0.2] + (["-e"] if eam else [])
+    sim = pkg.Simulation(args, host_only=True)
+    o = orc.Oracle(n, grid, eam=eam, delta=0.2, cap=sim.max_atoms)
+    lib = sim.lib
+    nbr, coord = sim.neighbor_ranks()
+    # 1. initial state of my brick == the oracle's virtual rank (lattice partition, allreduced COM removal + rescale)
+    c = sim.cells()
+    nl = sim.n_local_boxes
+    mine = {}
+    for b in range(nl):
+        for i in range(c["nAtoms"][b]):
+            mine[int(c["gid"][b, i])] = tuple(c[k][b, i] for k in ("px", "py", "pz"))
+    # the oracle has already redistributed; compare momenta by gid over the atoms I own now
+    allp = o.gather(orc.P)
+    for g, p in mine.items():
+        assert tuple(allp[g]) == p, (rank, g)
+
+    # 2. product's exchange driver with a numpy pack/unpack over gloo
+    cells_of = {f: sim.face_cells(0, f) for f in range(6)}
+    shift = {}
+    for f in range(6):
+        v = (ctypes.c_double * 3)()
+        lib.comdFaceShift(sim.ptr, f, v)
+        shift[f] = tuple(v)
+    h = lib.comdHostAtoms(sim.ptr).contents
+    cap, ntot = sim.max_atoms, sim.n_total_boxes
+
+    def view(ptr, dt):
+        return np.ctypeslib.as_array(ptr, shape=(ntot * cap,))
+
+    gid, spec = view(h.gid, np.int32), view(h.iSpecies, np.int32)
+    arr = {k: view(getattr(h, k), np.float64) for k in ("rx", "ry", "rz", "px", "py", "pz")}
+    nat = np.ctypeslib.as_array(h.nAtoms, shape=(ntot,))
+
+    # local rebinning on the host mirror (what updateLinkCellsGpu does on the device): re-insert every local atom by coordinate
+    recs = []
+    for b in range(nl):
+        for s in range(b * cap, b * cap + nat[b]):
+            recs.append((int(gid[s]), int(spec[s]), arr["rx"][s], arr["ry"][s], arr["rz"][s], arr["px"][s], arr["py"][s], arr["pz"][s]))
+    nat[:] = 0
+    for g_, t_, x, y, z, px, py, pz in recs:
+        lib.comdPutAtomInBox(sim.ptr, g_, t_, (ctypes.c_double * 3)(x, y, z), (ctypes.c_double * 3)(px, py, pz))
+
+    def load(parms, data, face, buf):
+        out = bytearray()
+        sx, sy, sz = shift[face]
+        for b in cells_of[face]:
+            for s in range(b * cap, b * cap + nat[b]):
+                out += REC.pack(int(gid[s]), int(spec[s]), arr["rx"][s] + sx, arr["ry"][s] + sy, arr["rz"][s] + sz,
+                                arr["px"][s], arr["py"][s], arr["pz"][s])
+        ctypes.memmove(buf, bytes(out), len(out))
+        return len(out)
+
+    def unload(parms, data, face, nbytes, buf):
+        raw = ctypes.string_at(buf, nbytes)
+        for k in range(nbytes // REC.size):
+            g_, t_, x, y, z, px, py, pz = REC.unpack_from(raw, k * REC.size)
+            lib.comdPutAtomInBox(sim.ptr, g_, t_, (ctypes.c_double * 3)(x, y, z), (ctypes.c_double * 3)(px, py, pz))
+
+    keep = (pkg.LOAD_FN(load), pkg.UNLOAD_FN(unload))
+    lib.comdHaloExchangeHost(sim.ptr, *keep)
+
+    oc = o.rank_cells(rank)
+    assert np.array_equal(nat, oc["nAtoms"]), (rank, np.nonzero(nat != oc["nAtoms"])[0][:10])
+    for b in range(ntot):
+        k = nat[b]
+        order = np.argsort(gid[b * cap:b * cap + k])
+        assert np.array_equal(gid[b * cap:b * cap + k][order], oc["gid"][b, :k]), (rank, b)
+        for name in ("rx", "ry", "rz", "px", "py", "pz"):
+            assert np.array_equal(arr[name][b * cap:b * cap + k][order], oc[name][b, :k]), (rank, b, name)
+    sim.close()
+    print(f"rank {rank}: host-mode OK ({sum(nat[:nl])} local atoms, {sum(nat[nl:])} halo atoms)")
+
+
+def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async):
+    import torch
+    pkg.setup_gpu(0, rank)
+    args = ["-x", n, "-y", n, "-z", n, "-i", grid[0], "-j", grid[1], "-k", grid[2], "-r", 0.1, "-m", method, "-a", use_async] + (["-e"] if eam else [])
+    sim = pkg.Simulation(args)
+    steps = 12
+
+    def gather_all(which):
+        a = torch.from_numpy(sim.gather(which))
+        dist.all_reduce(a)
+        return a.numpy()
+
+    f0 = gather_all(2)
+    e0 = sim.energy()
+    sim.step(steps)
+    r1, f1, e1 = gather_all(0), gather_all(2), sim.energy()
+    sim.sum_atoms()
+    assert sim.energy()[2] == 4 * n ** 3
+    if rank == 0:
+        o = orc.Oracle(n, grid, eam=eam, delta=0.1)
+        fo, eo = o.gather(orc.F), o.energy()
+        assert np.abs(f0 - fo).max() < 1e-11 * np.abs(fo).max()
+        assert abs(e0[0] - eo[0]) / e0[2] < 1e-11 and abs(e0[1] - eo[1]) / e0[2] < 1e-12
+        o.step(steps)
+        fo, eo = o.gather(orc.F), o.energy()
+        ro = o.gather(orc.R)
+        ext = n * 3.615
+        d = r1 - ro
+        d -= np.rint(d / ext) * ext                       # an atom may sit on either side of a periodic face
+        assert np.abs(d).max() < 1e-10
+        assert np.abs(f1 - fo).max() < 1e-9 * np.abs(fo).max()
+        assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < 2e-12
+        print(f"gpu-mode OK: {world} ranks {grid}, {'EAM' if eam else 'LJ'} {n}^3 {method} async={use_async}: E/atom {(e1[0]+e1[1])/e1[2]:.12f}")
+    sim.close()
+
+
+def main():
+    mode, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    grid = tuple(int(v) for v in sys.argv[5:8])
+    eam, n = int(sys.argv[8]), int(sys.argv[9])
+    method = sys.argv[10] if len(sys.argv) > 10 else "thread_atom"
+    use_async = int(sys.argv[11]) if len(sys.argv) > 11 else 0
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pkg, orc = ge.load_package(), ge.load_oracle()
+    transport = pkg.GlooTransport(dist)
+    pkg.init_parallel(rank, world, transport.struct)
+    if mode == "host":
+        host_mode(pkg, orc, transport, rank, world, grid, eam, n)
+    else:
+        gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
