@@ -205,6 +205,7 @@ extern "C" void SetBoundaryCells(SimGpu* sim, int nBoundary, const int* boundary
 extern "C" void CopyDataToGpu(SimGpu* sim, const HostAtoms* h)
 {
    const size_t slots = (size_t)sim->boxes.nTotalBoxes * sim->maxAtoms;
+   sim->max_atoms_cell = 0;                       // unknown until the next updateNAtomsCpu: launch cap/64 waves per cell
    HIP_CHECK(hipMemcpy(sim->boxes.nAtoms, h->nAtoms, (size_t)sim->boxes.nTotalBoxes * sizeof(int), hipMemcpyHostToDevice));
    HIP_CHECK(hipMemcpy(sim->atoms.gid, h->gid, slots * sizeof(int), hipMemcpyHostToDevice));
    HIP_CHECK(hipMemcpy(sim->atoms.iSpecies, h->iSpecies, slots * sizeof(int), hipMemcpyHostToDevice));
@@ -233,6 +234,9 @@ extern "C" void updateNAtomsCpu(SimGpu* sim, int* nAtomsHost)
 {
    HIP_CHECK(hipDeviceSynchronize());
    HIP_CHECK(hipMemcpy(nAtomsHost, sim->boxes.nAtoms, (size_t)sim->boxes.nTotalBoxes * sizeof(int), hipMemcpyDeviceToHost));
+   int m = 0;
+   for (int i = 0; i < sim->boxes.nTotalBoxes; ++i) if (nAtomsHost[i] > m) m = nAtomsHost[i];
+   sim->max_atoms_cell = m;                       // gpu_types.h:160 max_atoms_cell: sizes the LJ thread_atom workgroups
 }
 
 extern "C" void DestroyGpu(SimGpu* sim)
@@ -266,6 +270,7 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
       fprintf(stderr, "Rank %d, GPU: %d, %s: ", g_rank, sim->deviceId, where);
       if (st[0] & 1) fprintf(stderr, "a link cell overflowed its %d slots (raise --maxAtoms); ", sim->maxAtoms);
       if (st[0] & 2) fprintf(stderr, "a cell stencil holds more atoms than the cta_cell kernel can stage; ");
+      if (st[0] & 4) fprintf(stderr, "a cell outgrew SimGpu.max_atoms_cell + 16 between two occupancy refreshes (sumAtoms); ");
       if (st[1])     fprintf(stderr, "an atom moved beyond the halo region and was lost; ");
       if (st[2])     fprintf(stderr, "a halo message overflowed its buffer; ");
       fprintf(stderr, "\n");
@@ -298,6 +303,11 @@ static LjArgs makeLjArgs(SimGpu* sim, int num_cells, int* cells_list)
    return a;
 }
 
+// Per-atom energies are consumed only by computeEnergy.  The host announces with comdSetEnergyNeeded(0) that the coming
+// force evaluations feed no energy read (all but the last step of a timestep() call); the default is 1 (always compute).
+static int g_needEnergy = 1;
+extern "C" void comdSetEnergyNeeded(int on) { g_needEnergy = on; }
+
 extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream)
 {
    if (num_cells <= 0) return;
@@ -312,8 +322,23 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       if (27L * sim->maxAtoms > 65535) { fprintf(stderr, "ljForceGpu: cta_cell needs 27*maxAtoms < 65536\n"); exit(-1); }
       hipLaunchKernelGGL(LJ_Force_cta_cell, dim3(num_cells), dim3(LJ_CTA_THREADS), LJ_CTA_LDS_BYTES, S(stream), a, sim->status);
    } else {
-      const long waves = (long)num_cells * (sim->maxAtoms / 64);
-      hipLaunchKernelGGL(LJ_Force_thread_atom, dim3(ceilDiv(waves, 4)), dim3(256), 0, S(stream), a);
+      // Measured on MI355X (LJ 80^3): workgroup = cap/64 = 4 waves per cell with the tail wave exiting at once runs the kernel in
+      // 4.73 ms; sizing the workgroup to the 3 live waves (max_atoms_cell) 6.05 ms; single-wave workgroups 5.64 ms.  The waves of one
+      // cell walk the same neighbour data in step (shared scalar-cache lines), and fewer, wider workgroups keep that locality.
+      int w = sim->maxAtoms / 64;
+      { const char* e = getenv("COMD_LJ_WAVES"); if (!(e && atoi(e) == 0) && sim->max_atoms_cell > 0) { w = (sim->max_atoms_cell + 16 + 63) / 64; if (w > sim->maxAtoms / 64) w = sim->maxAtoms / 64; } }
+      if (w > 4) { fprintf(stderr, "ljForceGpu: thread_atom supports at most 256 atoms per cell\n"); exit(-1); }
+      static int ldsPad = -1;
+      if (ldsPad < 0) { const char* e = getenv("COMD_LJ_LDS"); ldsPad = e ? atoi(e) : 0; }
+      static int pipe = -1;
+      if (pipe < 0) { const char* e = getenv("COMD_LJ_PIPE"); pipe = e ? atoi(e) : 0; }
+      if (pipe) {
+         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, true>), dim3(num_cells), dim3(64 * w), ldsPad, S(stream), a, w, sim->status);
+         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, true>), dim3(num_cells), dim3(64 * w), ldsPad, S(stream), a, w, sim->status);
+      } else {
+         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, false>), dim3(num_cells), dim3(64 * w), ldsPad, S(stream), a, w, sim->status);
+         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, false>), dim3(num_cells), dim3(64 * w), ldsPad, S(stream), a, w, sim->status);
+      }
    }
    LAUNCH_CHECK();
 }

@@ -91,109 +91,201 @@ void EAM_Force_embed(EamArgs a)
 
 // ---------------------------------------------------------------------------------------------------
 // wave per cell, tables in LDS.
+//
+// Per cell the wave (1) prefix-sums the occupancies of the 27 stencil cells, (2) stages their positions (and F' in
+// pass 3), compacted, into its LDS slice -- all global loads of a group of rounds are issued before the first is consumed,
+// so the HBM/L2 latency is paid a few times per cell, not 27 times -- (4) for each i atom: 3 LDS reads + 7 VALU ops per
+// candidate tile of 64, v_cmp mask -> mbcnt
+// compaction into a 128-entry LDS queue, evaluation of the accepted pairs at full lane occupancy, (5) reduces the per-lane
+// partial sums of TWO atoms at a time with a transposed butterfly (1 merge level + 5 xor steps instead of 2 x 6 steps).
 #define EAM_CTA_THREADS 256
 #define EAM_CTA_WAVES   4
-#define EAM_CTA_MAXCAND 512          // candidates (atoms in the 27 stencil cells) one wave can stage
+#define EAM_CTA_MAXCAND 352                        // stencil atoms a wave can stage (FCC Cu at 80^3: 283 on average); sized for 3 workgroups per CU
 #define EAM_CTA_QUEUE   128
+
+// A cell whose 27-cell stencil holds more than EAM_CTA_MAXCAND atoms (small boxes have larger cells) is handled by the
+// same wave in the thread-per-atom form: lane = i atom, neighbours streamed from global memory, tables still in LDS.
+template <int STEP>
+__device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int lane, const TableView& rhoT, const TableView& phiT)
+{
+   const int ni = a.nAtoms[iBox];
+   const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
+   for (int i = lane; i < ni; i += 64) {
+      const size_t iOff = (size_t)iBox * a.cap + i;
+      const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+      double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0, dfi = 0.0;
+      if (STEP == 3) { fx = a.fx[iOff]; fy = a.fy[iOff]; fz = a.fz[iOff]; dfi = a.dfEmbed[iOff]; }
+      for (int k = 0; k < 27; ++k) {
+         const int jBox = nb[k];
+         const int nj = a.nAtoms[jBox];
+         const size_t base = (size_t)jBox * a.cap;
+         for (int j = 0; j < nj; ++j) {
+            const double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
+            const double r2 = dx*dx + dy*dy + dz*dz;
+            if (r2 <= a.rc2 && r2 > 0.0) {
+               const double ir = rsqrt64(r2), r = r2 * ir;
+               double rho, drho, dphi;
+               interpolate(rhoT, r, rho, drho);
+               if (STEP == 1) { double phi; interpolate(phiT, r, phi, dphi); e += phi; rb += rho; }
+               else           { dphi = (dfi + a.dfEmbed[base + j]) * drho; }
+               dphi *= ir;
+               fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
+            }
+         }
+      }
+      a.fx[iOff] = fx; a.fy[iOff] = fy; a.fz[iOff] = fz;
+      if (STEP == 1) { a.e[iOff] = 0.5 * e; a.rhobar[iOff] = rb; }
+   }
+}
+
+// merge the per-lane partial sums of two atoms across the lane bit `BIT`: lanes with the bit clear end up holding
+// atom A's sums, lanes with it set atom B's, each already added over the lane pair (l, l ^ BIT)
+template <int BIT>
+__device__ __forceinline__ double mergePair(double pa, double pb, int lane)
+{
+   const bool hi = (lane & BIT) != 0;
+   const double keep = hi ? pb : pa;
+   const double send = hi ? pa : pb;
+   return keep + bpermute64(send, lane ^ BIT);
+}
 
 template <int STEP>
 __global__ __launch_bounds__(EAM_CTA_THREADS)
 void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-   // layout: rho table | phi table (pass 1) | per wave: x,y,z[,df] candidates, queue, offsets
+   constexpr int NV = (STEP == 1) ? 5 : 3;                   // values reduced per atom: f (3) [+ e, rhobar]
+   constexpr int NC = (STEP == 1) ? 3 : 4;                   // doubles staged per candidate: r (3) [+ F']
    const int nRhoPad = a.rho.n + 3, nPhiPad = (STEP == 1) ? a.phi.n + 3 : 0;
    double* sRho = (double*)ldsRaw;
    double* sPhi = sRho + nRhoPad;
    double* waveBase = sPhi + nPhiPad;
-   const int perWaveDoubles = (STEP == 1 ? 3 : 4) * EAM_CTA_MAXCAND;
+   constexpr int perWaveDoubles = NC * EAM_CTA_MAXCAND + (EAM_CTA_QUEUE * 2 + 64 * 4) / 8;
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-   double* sx = waveBase + (size_t)wave * (perWaveDoubles + (EAM_CTA_QUEUE * 2 + 32 * 4) / 8);
+   double* sx = waveBase + (size_t)wave * perWaveDoubles;
    double* sy = sx + EAM_CTA_MAXCAND;
    double* sz = sy + EAM_CTA_MAXCAND;
-   double* sdf = sz + EAM_CTA_MAXCAND;                       // pass 3 only
-   unsigned short* q = (unsigned short*)(sx + perWaveDoubles);
-   int* sOff = (int*)(q + EAM_CTA_QUEUE);                    // [28]... stored as 32 ints
+   double* sdf = sz + EAM_CTA_MAXCAND;                       // pass 3 only (aliases the queue region in pass 1: not used there)
+   unsigned short* q = (unsigned short*)(sx + NC * EAM_CTA_MAXCAND);
+   int* sOff = (int*)(q + EAM_CTA_QUEUE);                    // [32] exclusive candidate offsets of the stencil cells
+   int* sBox = sOff + 32;                                    // [32] their cell ids
 
    for (int t = threadIdx.x; t < nRhoPad; t += EAM_CTA_THREADS) sRho[t] = a.rho.values[t];
    if (STEP == 1) for (int t = threadIdx.x; t < nPhiPad; t += EAM_CTA_THREADS) sPhi[t] = a.phi.values[t];
    __syncthreads();
    const TableView rhoT = makeTable(a.rho, sRho), phiT = makeTable(a.phi, sPhi);
 
+   // cap is a power of two <= 64 for EAM (chooseMaxAtoms): `cellsPerRound` stencil cells are staged per round of 64 lanes
+   const int capShift = 31 - __builtin_clz(a.cap);
+   const int cellsPerRound = 64 >> capShift;
+   const int myK = lane >> capShift, myJ = lane & (a.cap - 1);
+
    for (int ci = blockIdx.x * EAM_CTA_WAVES + wave; ci < a.nCells; ci += gridDim.x * EAM_CTA_WAVES) {
       const int iBox = uniform(a.cells ? a.cells[ci] : ci);
       const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
-      // candidate offsets of the 27 stencil cells (own cell first)
-      int myBox = lane < 27 ? nb[lane] : 0;
-      int cnt = lane < 27 ? a.nAtoms[myBox] : 0;
-      int incl = cnt;
+      // (1) candidate offsets, own cell first
+      {
+         const int box = lane < 27 ? nb[lane] : 0;
+         const int cnt = lane < 27 ? a.nAtoms[box] : 0;
+         int incl = cnt;
 #pragma unroll
-      for (int d = 1; d < 32; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-      if (lane < 27) sOff[lane] = incl - cnt;
-      if (lane == 26) sOff[27] = incl;
+         for (int d = 1; d < 32; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+         if (lane < 28) { sOff[lane] = incl - cnt; sBox[lane] = box; }     // lane 27: cnt = 0 -> sOff[27] = total
+      }
       __builtin_amdgcn_wave_barrier();
       const int nCand = uniform(sOff[27]);
-      const int ni = uniform(sOff[1]);                       // own cell's count
-      if (nCand > EAM_CTA_MAXCAND) { if (lane == 0) atomicOr(&status[0], 2); continue; }
-      for (int k = 0; k < 27; ++k) {
-         const int jBox = uniform(nb[k]);
-         const int off = uniform(sOff[k]), nj = uniform(sOff[k + 1]) - off;
-         for (int j = lane; j < nj; j += 64) {
-            size_t o = (size_t)jBox * a.cap + j;
-            sx[off + j] = a.rx[o]; sy[off + j] = a.ry[o]; sz[off + j] = a.rz[o];
-            if (STEP == 3) sdf[off + j] = a.dfEmbed[o];
+      const int ni = uniform(sOff[1]);
+      if (nCand > EAM_CTA_MAXCAND) { eamCellDirect<STEP>(a, iBox, lane, rhoT, phiT); continue; }
+
+      // (2) stage positions [and F'] of the stencil cells, in groups of GROUP rounds with all loads in flight together
+      constexpr int GROUP = 4;                      // 4 rounds x (3-4 loads) in flight; 7 rounds cost 60 more VGPRs and a wave per SIMD
+      for (int k0 = 0; k0 < 27; k0 += GROUP * cellsPerRound) {
+         double vx[GROUP], vy[GROUP], vz[GROUP], vd[GROUP];
+         int dst[GROUP];
+#pragma unroll
+         for (int g = 0; g < GROUP; ++g) {
+            const int k = k0 + g * cellsPerRound + myK;
+            dst[g] = -1;
+            if (k < 27) {
+               const int off = sOff[k], n = sOff[k + 1] - off;
+               if (myJ < n) {
+                  const size_t o = (size_t)sBox[k] * a.cap + myJ;
+                  vx[g] = a.rx[o]; vy[g] = a.ry[o]; vz[g] = a.rz[o];
+                  if (STEP == 3) vd[g] = a.dfEmbed[o];
+                  dst[g] = off + myJ;
+               }
+            }
          }
+#pragma unroll
+         for (int g = 0; g < GROUP; ++g)
+            if (dst[g] >= 0) {
+               sx[dst[g]] = vx[g]; sy[dst[g]] = vy[g]; sz[dst[g]] = vz[g];
+               if (STEP == 3) sdf[dst[g]] = vd[g];
+            }
       }
       __builtin_amdgcn_wave_barrier();
 
-      for (int i = 0; i < ni; ++i) {
-         const double xi = sx[i], yi = sy[i], zi = sz[i];
-         const double dfi = (STEP == 3) ? sdf[i] : 0.0;
-         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0;
-         int qn = 0;
-         auto evalPair = [&](int jj) {
-            double dx = xi - sx[jj], dy = yi - sy[jj], dz = zi - sz[jj];
-            double r2 = dx*dx + dy*dy + dz*dz;
-            double ir = rsqrt64(r2), r = r2 * ir;
-            double rho, drho, dphi;
-            interpolate(rhoT, r, rho, drho);
-            if (STEP == 1) { double phi; interpolate(phiT, r, phi, dphi); e += phi; rb += rho; }
-            else           { dphi = (dfi + sdf[jj]) * drho; }
-            dphi *= ir;
-            fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
-         };
-         for (int j0 = 0; j0 < nCand; j0 += 64) {
-            const int j = j0 + lane;
-            bool hit = false;
-            if (j < nCand) {
-               double dx = xi - sx[j], dy = yi - sy[j], dz = zi - sz[j];
-               double r2 = dx*dx + dy*dy + dz*dz;
-               hit = (r2 <= a.rc2) && (r2 > 0.0);
-            }
-            const unsigned long long m = __ballot(hit);
-            if (hit) {
-               int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-               q[pos] = (unsigned short)j;
-            }
-            qn += __popcll(m);
-            __builtin_amdgcn_wave_barrier();
-            if (qn >= 64) {
-               evalPair(q[lane]);
-               qn -= 64;
-               const unsigned short carry = q[64 + lane];
+      const int nTiles = (nCand + 63) >> 6;
+
+      // (4)+(5) two i atoms per round
+      for (int i0 = 0; i0 < ni; i0 += 2) {
+         double part[2][NV];
+#pragma unroll
+         for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) part[u][v] = 0.0;
+            const int i = i0 + u;
+            if (i < ni) {                                             // wave-uniform
+               const double xi = sx[i], yi = sy[i], zi = sz[i];
+               const double dfi = (STEP == 3) ? sdf[i] : 0.0;
+               int qn = 0;
+               for (int t = 0; t < nTiles; ++t) {
+                  {
+                     const int c = t * 64 + lane;
+                     const int cc = c < nCand ? c : 0;                  // lanes past the list re-read candidate 0 and are masked
+                     const double dx = xi - sx[cc], dy = yi - sy[cc], dz = zi - sz[cc];
+                     const double r2 = dx*dx + dy*dy + dz*dz;
+                     const bool hit = (r2 <= a.rc2) && (r2 > 0.0) && (c < nCand);
+                     const unsigned long long m = __ballot(hit);
+                     if (hit) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)(t * 64 + lane);
+                     qn += __popcll(m);
+                  }
+               }
                __builtin_amdgcn_wave_barrier();
-               if (lane < qn) q[lane] = carry;
+               // accepted pairs: 64 per batch (one batch for FCC Cu: 42 neighbours inside the cutoff)
+               for (int b = 0; b < qn; b += 64) {
+                  if (b + lane < qn) {
+                     const int jj = q[b + lane];
+                     const double dx = xi - sx[jj], dy = yi - sy[jj], dz = zi - sz[jj];
+                     const double r2 = dx*dx + dy*dy + dz*dz;
+                     const double ir = rsqrt64(r2), r = r2 * ir;
+                     double rho, drho, dphi;
+                     interpolate(rhoT, r, rho, drho);
+                     if (STEP == 1) { double phi; interpolate(phiT, r, phi, dphi); part[u][3] += phi; part[u][4] += rho; }
+                     else           { dphi = (dfi + sdf[jj]) * drho; }
+                     dphi *= ir;
+                     part[u][0] -= dphi * dx; part[u][1] -= dphi * dy; part[u][2] -= dphi * dz;
+                  }
+               }
                __builtin_amdgcn_wave_barrier();
             }
          }
-         if (lane < qn) evalPair(q[lane]);
-         __builtin_amdgcn_wave_barrier();
-         fx = waveSum(fx); fy = waveSum(fy); fz = waveSum(fz);
-         if (STEP == 1) { e = waveSum(e); rb = waveSum(rb); }
-         if (lane == 0) {
-            const size_t io = (size_t)iBox * a.cap + i;
-            if (STEP == 1) { a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = 0.5 * e; a.rhobar[io] = rb; }
-            else           { a.fx[io] += fx; a.fy[io] += fy; a.fz[io] += fz; }
+         // transposed reduction: afterwards lane 0 holds the totals of atom i0, lane 32 those of atom i0 + 1
+         double tot[NV];
+#pragma unroll
+         for (int v = 0; v < NV; ++v) {
+            double s2 = mergePair<32>(part[0][v], part[1][v], lane);
+#pragma unroll
+            for (int m = 16; m >= 1; m >>= 1) s2 += bpermute64(s2, lane ^ m);
+            tot[v] = s2;
+         }
+         if ((lane & 31) == 0) {
+            const int i = i0 + (lane >> 5);
+            if (i < ni) {
+               const size_t io = (size_t)iBox * a.cap + i;
+               if (STEP == 1) { a.fx[io] = tot[0]; a.fy[io] = tot[1]; a.fz[io] = tot[2]; a.e[io] = 0.5 * tot[3]; a.rhobar[io] = tot[4]; }
+               else           { a.fx[io] += tot[0]; a.fy[io] += tot[1]; a.fz[io] += tot[2]; }
+            }
          }
       }
       __builtin_amdgcn_wave_barrier();
@@ -203,6 +295,6 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 static inline size_t eamCtaLdsBytes(int step, int nRho, int nPhi)
 {
    size_t tables = (size_t)(nRho + 3 + (step == 1 ? nPhi + 3 : 0)) * 8;
-   size_t perWave = (size_t)(step == 1 ? 3 : 4) * EAM_CTA_MAXCAND * 8 + EAM_CTA_QUEUE * 2 + 32 * 4;
+   size_t perWave = (size_t)(step == 1 ? 3 : 4) * EAM_CTA_MAXCAND * 8 + EAM_CTA_QUEUE * 2 + 64 * 4;
    return tables + EAM_CTA_WAVES * perWave;
 }

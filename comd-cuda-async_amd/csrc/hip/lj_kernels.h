@@ -26,18 +26,22 @@ struct LjArgs {
    double rc2, s6, eShift, eps;
 };
 
+// One accepted pair.  With u = s6 / r^6:  e_pair = u (u - 1) - eShift,  f_pair = 24 u (2u - 1) / r^2 * d.
+// The constant factors (24 eps on the force, 4 eps * 1/2 on the energy) are applied once per atom by the caller.
+// ENERGY = false drops the energy ops: e[] is only consumed by computeEnergy, i.e. by the last step of a timestep() call.
+template <bool ENERGY>
 __device__ __forceinline__ void ljPair(double dx, double dy, double dz, double r2, const LjArgs& a,
                                        double& fx, double& fy, double& fz, double& e)
 {
-   double ir2 = rcp64(r2);
-   double r6 = a.s6 * (ir2 * ir2 * ir2);
-   e += 0.5 * (r6 * (r6 - 1.0) - a.eShift);
-   double fr = r6 * ir2 * (48.0 * r6 - 24.0);
-   fx += fr * dx; fy += fr * dy; fz += fr * dz;
+   const double ir2 = rcp64(r2);
+   const double u = a.s6 * ir2 * ir2 * ir2;
+   if (ENERGY) e += __builtin_fma(u, u - 1.0, -a.eShift);
+   const double fr = u * ir2 * __builtin_fma(u, 2.0, -1.0);
+   fx = __builtin_fma(fr, dx, fx); fy = __builtin_fma(fr, dy, fy); fz = __builtin_fma(fr, dz, fz);
 }
 
 // one neighbour cell against the wave's 64 i atoms; SELF adds the r2 > 0 guard of the own cell
-template <bool SELF>
+template <bool SELF, bool ENERGY>
 __device__ __forceinline__ void ljCellLoop(const LjArgs& a, int jBox, double xi, double yi, double zi,
                                            double& fx, double& fy, double& fz, double& e)
 {
@@ -56,27 +60,56 @@ __device__ __forceinline__ void ljCellLoop(const LjArgs& a, int jBox, double xi,
          double dx = xi - xs[u], dy = yi - ys[u], dz = zi - zs[u];
          double r2 = dx*dx + dy*dy + dz*dz;
          bool hit = SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2);
-         if (hit) ljPair(dx, dy, dz, r2, a, fx, fy, fz, e);
+         if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
       }
    }
    for (; j < nj; ++j) {
       double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
       double r2 = dx*dx + dy*dy + dz*dz;
       bool hit = SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2);
-      if (hit) ljPair(dx, dy, dz, r2, a, fx, fy, fz, e);
+      if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+   }
+}
+
+// same, software pipelined: the scalar loads of batch b+1 (4 neighbours) are issued before batch b is evaluated
+template <bool SELF, bool ENERGY>
+__device__ __forceinline__ void ljCellLoopPipelined(const LjArgs& a, int jBox, double xi, double yi, double zi,
+                                                    double& fx, double& fy, double& fz, double& e)
+{
+   const int nj = uniform(a.nAtoms[jBox]);
+   const double* __restrict__ px = a.rx + (size_t)jBox * a.cap;
+   const double* __restrict__ py = a.ry + (size_t)jBox * a.cap;
+   const double* __restrict__ pz = a.rz + (size_t)jBox * a.cap;
+   // the slot arrays are padded to cap >= nj rounded up to 4 (cap % 64 == 0), so reading one batch past nj is in bounds
+   double xs[4], ys[4], zs[4], xn[4], yn[4], zn[4];
+#pragma unroll
+   for (int u = 0; u < 4; ++u) { xs[u] = px[u]; ys[u] = py[u]; zs[u] = pz[u]; }
+   for (int j = 0; j < nj; j += 4) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { xn[u] = px[j + 4 + u]; yn[u] = py[j + 4 + u]; zn[u] = pz[j + 4 + u]; }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+         double dx = xi - xs[u], dy = yi - ys[u], dz = zi - zs[u];
+         double r2 = dx*dx + dy*dy + dz*dz;
+         bool hit = (SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2)) && (j + u < nj);
+         if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { xs[u] = xn[u]; ys[u] = yn[u]; zs[u] = zn[u]; }
    }
 }
 
 // ---------------------------------------------------------------------------------------------------
 // thread per atom, wave per 64-slot chunk of a cell.  Requires cap % 64 == 0.
-// grid: ceil(nCells * (cap/64) / 4) blocks of 256 threads.
+// grid: one workgroup of `wavesPerCell` waves per cell, where wavesPerCell = ceil((largest occupancy + slack) / 64) as
+// last seen by the host (SimGpu.max_atoms_cell) -- 3 waves for 5-sigma LJ Cu instead of cap/64 = 4, so no wave is born dead.
+// A cell that outgrew that bound raises status bit 4 (checked with the other flags at the next energy read).
+template <bool ENERGY, bool PIPE>
 __global__ __launch_bounds__(256)
-void LJ_Force_thread_atom(LjArgs a)
+void LJ_Force_thread_atom(LjArgs a, int wavesPerCell, int* __restrict__ status)
 {
    const int lane = threadIdx.x & 63;
-   const int wavesPerCell = a.cap >> 6;
-   const int bid = xcdRemap(blockIdx.x, gridDim.x);
-   const int gw = uniform(bid * 4 + (threadIdx.x >> 6));
+   const int gw = uniform(xcdRemap(blockIdx.x, gridDim.x) * wavesPerCell + (threadIdx.x >> 6));
    const int ci = gw / wavesPerCell;
    const int chunk = gw - ci * wavesPerCell;
    if (ci >= a.nCells) return;
@@ -91,13 +124,23 @@ void LJ_Force_thread_atom(LjArgs a)
    double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
 
    const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
-   ljCellLoop<true>(a, iBox, xi, yi, zi, fx, fy, fz, e);
-   for (int k = 1; k < 27; ++k) ljCellLoop<false>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
+   if (PIPE) {
+      ljCellLoopPipelined<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
+      for (int k = 1; k < 27; ++k) ljCellLoopPipelined<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
+   } else {
+      ljCellLoop<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
+      for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
+   }
 
    if (active) {
-      a.fx[iOff] = fx * a.eps; a.fy[iOff] = fy * a.eps; a.fz[iOff] = fz * a.eps;
-      a.e[iOff] = e * 4.0 * a.eps;
+      const double fs = 24.0 * a.eps;
+      a.fx[iOff] = fx * fs; a.fy[iOff] = fy * fs; a.fz[iOff] = fz * fs;
+      if (ENERGY) a.e[iOff] = e * 2.0 * a.eps;          // 4 eps * 1/2 per pair
    }
+   // NOTE: every store/atomic of this kernel sits below its last load.  A store above the neighbour loop makes the compiler
+   // give up proving the position arrays unclobbered and it silently replaces the s_load_dwordx16 stream by per-lane
+   // global_load (measured: 4.7 ms -> 6.2 ms).
+   if (ni > wavesPerCell * 64 && chunk == 0 && lane == 0) atomicOr(&status[0], 4);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -175,7 +218,7 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status)
          if (qn >= 64) {                                    // evaluate one full batch at 64/64 lanes
             const int jj = q[lane];
             double dx = xi - sx[jj], dy = yi - sy[jj], dz = zi - sz[jj];
-            ljPair(dx, dy, dz, dx*dx + dy*dy + dz*dz, a, fx, fy, fz, e);
+            ljPair<true>(dx, dy, dz, dx*dx + dy*dy + dz*dz, a, fx, fy, fz, e);
             qn -= 64;
             const unsigned short carry = q[64 + lane];      // move the overflow to the front
             __builtin_amdgcn_wave_barrier();
@@ -186,14 +229,15 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status)
       if (lane < qn) {                                      // tail batch
          const int jj = q[lane];
          double dx = xi - sx[jj], dy = yi - sy[jj], dz = zi - sz[jj];
-         ljPair(dx, dy, dz, dx*dx + dy*dy + dz*dz, a, fx, fy, fz, e);
+         ljPair<true>(dx, dy, dz, dx*dx + dy*dy + dz*dz, a, fx, fy, fz, e);
       }
       __builtin_amdgcn_wave_barrier();
       fx = waveSum(fx); fy = waveSum(fy); fz = waveSum(fz); e = waveSum(e);
       if (lane == 0) {
          const size_t io = (size_t)iBox * a.cap + i;
-         a.fx[io] = fx * a.eps; a.fy[io] = fy * a.eps; a.fz[io] = fz * a.eps;
-         a.e[io] = e * 4.0 * a.eps;
+         const double fs = 24.0 * a.eps;
+         a.fx[io] = fx * fs; a.fy[io] = fy * fs; a.fz[io] = fz * fs;
+         a.e[io] = e * 2.0 * a.eps;
       }
    }
 }

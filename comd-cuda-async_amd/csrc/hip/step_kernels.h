@@ -217,7 +217,20 @@ void UnloadAtomsBufferPacked(const char* __restrict__ msg, int nBuf, int capacit
    const CellGeom g = makeGeom(boxes);
    if (!comdCoordInHalo(&g, x, y, z)) { atomicOr(&status[1], 1); return; }
    const int c = comdBoxFromCoord(&g, x, y, z);
-   const int slot = atomicAdd(&nAtoms[c], 1);
+   // The message is cell ordered, so most lanes of a wave target the same cell: one atomic per distinct cell per wave
+   // (leader adds the group's size, members take consecutive slots) instead of 64 serialized same-address atomics.
+   int slot = 0;
+   for (bool pending = true; pending; ) {
+      const int lead = __builtin_amdgcn_readfirstlane(c);
+      if (c == lead) {
+         const unsigned long long m = __ballot(1);
+         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+         int base = 0;
+         if (rank == 0) base = atomicAdd(&nAtoms[lead], __popcll(m));
+         slot = __builtin_amdgcn_readfirstlane(base) + rank;
+         pending = false;
+      }
+   }
    if (slot >= cap) { atomicOr(&status[0], 1); return; }
    const size_t d = (size_t)c * cap + slot;
    at.gid[d] = mg[i]; at.spec[d] = mt[i];

@@ -19,6 +19,9 @@ double timestep(SimFlat* s, int nSteps, real_t dt)
       advancePosition(s, dt);
       stopTimer(positionTimer);
 
+      /* e[] is read by kineticEnergyGpu below only: the last step's forces must carry energies, the others need not
+       * (set before redistributeAtoms: with -a 1 it already launches the interior cells' force work) */
+      comdSetEnergyNeeded(ii == nSteps - 1);
       startTimer(redistributeTimer);
       redistributeAtoms(s);
       stopTimer(redistributeTimer);
@@ -26,6 +29,7 @@ double timestep(SimFlat* s, int nSteps, real_t dt)
       startTimer(computeForceTimer);
       computeForce(s);
       stopTimer(computeForceTimer);
+      comdSetEnergyNeeded(1);
 
       startTimer(velocityTimer);
       advanceVelocity(s, 0.5 * dt);

@@ -72,6 +72,7 @@ typedef struct AtomsGpu {
 /* gpu_types.h:159-190.  Passed by pointer everywhere (the reference passes 856 bytes by value). */
 typedef struct SimGpu {
    int          maxAtoms;              /* slot capacity of a link cell (Makefile:16 MAXATOMS) */
+   int          max_atoms_cell;        /* largest occupancy last seen by updateNAtomsCpu (gpu_types.h:160); 0 = unknown */
    int          deviceId, rank;
    AtomsGpu     atoms;
    int*         neighbor_cells;        /* device [nLocalBoxes*27], self first (gpu_utility.c:520-531) */
@@ -159,6 +160,10 @@ void comdCheckStatus(SimGpu* sim, const char* where);
  * signature parity and must be 0 (table-LJ and pairlists are out of scope): non-zero exits. */
 void ljForceGpu(SimGpu* sim, int interpolation, int num_cells, int* cells_list, real_t plcutoff, int method);
 void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream);
+/* The per-atom energy array e[] is read only by computeEnergy.  comdSetEnergyNeeded(0) tells the force wrappers that the
+ * next evaluations feed no energy read, so they may skip the energy arithmetic; comdSetEnergyNeeded(1) (the default)
+ * restores the reference behaviour of computing e[] on every call.  timestep() brackets all but its last step with it. */
+void comdSetEnergyNeeded(int on);
 /* eamForce{1,2,3}Gpu(SimGpu, method, spline), gpu_kernels.cu:154-249; spline must be 0 */
 void eamForce1Gpu(SimGpu* sim, int method, int spline);
 void eamForce2Gpu(SimGpu* sim, int method, int spline);
