@@ -53,6 +53,48 @@ __device__ __forceinline__ double waveSum(double v)
    return v;
 }
 
+// ---- DPP / permlane reductions: pure VALU, no trip through the LDS crossbar --------------------------------------
+// dpp_ctrl encodings (gfx9): quad_perm 0x00-0xFF, row_ror:n 0x120+n, row_bcast:15 0x142, row_bcast:31 0x143
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dppMove64(double v)       // lanes not written by the DPP pattern receive 0.0
+{
+   int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+   int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+   return __hiloint2double(hi, lo);
+}
+
+// sum within each row of 16 lanes; every lane of the row ends with the row total
+__device__ __forceinline__ double rowSum(double v)
+{
+   v += dppMove64<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+   v += dppMove64<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+   v += dppMove64<0x124, 0xF>(v);      // row_ror:4
+   v += dppMove64<0x128, 0xF>(v);      // row_ror:8
+   return v;
+}
+
+// Two atoms at once: pa / pb are per-lane partial sums of atoms A and B.  v_permlane32_swap exchanges the upper half of
+// pa with the lower half of pb, so one add leaves A's sums in lanes 0-31 and B's in lanes 32-63; rows are then summed
+// with DPP and row_bcast:15 folds row 0 into row 1 and row 2 into row 3.  Lane 31 holds A's total, lane 63 B's.
+__device__ __forceinline__ double pairSum(double pa, double pb)
+{
+   auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(pa), (unsigned)__double2loint(pb), false, false);
+   auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(pa), (unsigned)__double2hiint(pb), false, false);
+   double v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+   v = rowSum(v);
+   v += dppMove64<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+   return v;
+}
+
+// whole wave: lane 63 holds the total
+__device__ __forceinline__ double waveSumToLane63(double v)
+{
+   v = rowSum(v);
+   v += dppMove64<0x142, 0xA>(v);      // row_bcast:15 -> rows 1, 3
+   v += dppMove64<0x143, 0xC>(v);      // row_bcast:31 -> rows 2, 3
+   return v;
+}
+
 __device__ __forceinline__ int waveSumInt(int v)
 {
 #pragma unroll

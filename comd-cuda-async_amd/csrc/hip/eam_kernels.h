@@ -97,7 +97,7 @@ void EAM_Force_embed(EamArgs a)
 // so the HBM/L2 latency is paid a few times per cell, not 27 times -- (4) for each i atom: 3 LDS reads + 7 VALU ops per
 // candidate tile of 64, v_cmp mask -> mbcnt
 // compaction into a 128-entry LDS queue, evaluation of the accepted pairs at full lane occupancy, (5) reduces the per-lane
-// partial sums of TWO atoms at a time with a transposed butterfly (1 merge level + 5 xor steps instead of 2 x 6 steps).
+// partial sums of TWO atoms at a time: v_permlane32_swap puts one atom in each half of the wave, DPP row ops finish (no LDS).
 #define EAM_CTA_THREADS 256
 #define EAM_CTA_WAVES   4
 #define EAM_CTA_MAXCAND 352                        // stencil atoms a wave can stage (FCC Cu at 80^3: 283 on average); sized for 3 workgroups per CU
@@ -160,14 +160,14 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
    double* sRho = (double*)ldsRaw;
    double* sPhi = sRho + nRhoPad;
    double* waveBase = sPhi + nPhiPad;
-   constexpr int perWaveDoubles = NC * EAM_CTA_MAXCAND + (EAM_CTA_QUEUE * 2 + 64 * 4) / 8;
+   constexpr int perWaveDoubles = NC * EAM_CTA_MAXCAND + (2 * EAM_CTA_QUEUE * 2 + 64 * 4) / 8;
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
    double* sx = waveBase + (size_t)wave * perWaveDoubles;
    double* sy = sx + EAM_CTA_MAXCAND;
    double* sz = sy + EAM_CTA_MAXCAND;
    double* sdf = sz + EAM_CTA_MAXCAND;                       // pass 3 only (aliases the queue region in pass 1: not used there)
-   unsigned short* q = (unsigned short*)(sx + NC * EAM_CTA_MAXCAND);
-   int* sOff = (int*)(q + EAM_CTA_QUEUE);                    // [32] exclusive candidate offsets of the stencil cells
+   unsigned short* qBase = (unsigned short*)(sx + NC * EAM_CTA_MAXCAND);    // one pair queue per atom of a group: their work can interleave
+   int* sOff = (int*)(qBase + 2 * EAM_CTA_QUEUE);           // [32] exclusive candidate offsets of the stencil cells
    int* sBox = sOff + 32;                                    // [32] their cell ids
 
    for (int t = threadIdx.x; t < nRhoPad; t += EAM_CTA_THREADS) sRho[t] = a.rho.values[t];
@@ -235,6 +235,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 #pragma unroll
             for (int v = 0; v < NV; ++v) part[u][v] = 0.0;
             const int i = i0 + u;
+            unsigned short* q = qBase + u * EAM_CTA_QUEUE;
             if (i < ni) {                                             // wave-uniform
                const double xi = sx[i], yi = sy[i], zi = sz[i];
                const double dfi = (STEP == 3) ? sdf[i] : 0.0;
@@ -251,7 +252,6 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
                      qn += __popcll(m);
                   }
                }
-               __builtin_amdgcn_wave_barrier();
                // accepted pairs: 64 per batch (one batch for FCC Cu: 42 neighbours inside the cutoff)
                for (int b = 0; b < qn; b += 64) {
                   if (b + lane < qn) {
@@ -267,19 +267,13 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
                      part[u][0] -= dphi * dx; part[u][1] -= dphi * dy; part[u][2] -= dphi * dz;
                   }
                }
-               __builtin_amdgcn_wave_barrier();
             }
          }
-         // transposed reduction: afterwards lane 0 holds the totals of atom i0, lane 32 those of atom i0 + 1
+         // two-atom reduction (permlane32 swap + DPP): lane 31 holds the totals of atom i0, lane 63 those of atom i0 + 1
          double tot[NV];
 #pragma unroll
-         for (int v = 0; v < NV; ++v) {
-            double s2 = mergePair<32>(part[0][v], part[1][v], lane);
-#pragma unroll
-            for (int m = 16; m >= 1; m >>= 1) s2 += bpermute64(s2, lane ^ m);
-            tot[v] = s2;
-         }
-         if ((lane & 31) == 0) {
+         for (int v = 0; v < NV; ++v) tot[v] = pairSum(part[0][v], part[1][v]);
+         if ((lane & 31) == 31) {
             const int i = i0 + (lane >> 5);
             if (i < ni) {
                const size_t io = (size_t)iBox * a.cap + i;
@@ -295,6 +289,6 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 static inline size_t eamCtaLdsBytes(int step, int nRho, int nPhi)
 {
    size_t tables = (size_t)(nRho + 3 + (step == 1 ? nPhi + 3 : 0)) * 8;
-   size_t perWave = (size_t)(step == 1 ? 3 : 4) * EAM_CTA_MAXCAND * 8 + EAM_CTA_QUEUE * 2 + 64 * 4;
+   size_t perWave = (size_t)(step == 1 ? 3 : 4) * EAM_CTA_MAXCAND * 8 + 2 * EAM_CTA_QUEUE * 2 + 64 * 4;
    return tables + EAM_CTA_WAVES * perWave;
 }
