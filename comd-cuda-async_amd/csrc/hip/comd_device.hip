@@ -327,17 +327,18 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       // cell walk the same neighbour data in step (shared scalar-cache lines), and fewer, wider workgroups keep that locality.
       int w = sim->maxAtoms / 64;
       { const char* e = getenv("COMD_LJ_WAVES"); if (!(e && atoi(e) == 0) && sim->max_atoms_cell > 0) { w = (sim->max_atoms_cell + 16 + 63) / 64; if (w > sim->maxAtoms / 64) w = sim->maxAtoms / 64; } }
-      if (w > 4) { fprintf(stderr, "ljForceGpu: thread_atom supports at most 256 atoms per cell\n"); exit(-1); }
+      const int wavesPerBlock = w <= 4 ? w : 4;
+      const unsigned nBlocks = w <= 4 ? (unsigned)num_cells : (unsigned)ceilDiv((long)num_cells * w, 4);
       static int ldsPad = -1;
       if (ldsPad < 0) { const char* e = getenv("COMD_LJ_LDS"); ldsPad = e ? atoi(e) : 0; }
       static int pipe = -1;
       if (pipe < 0) { const char* e = getenv("COMD_LJ_PIPE"); pipe = e ? atoi(e) : 0; }
       if (pipe) {
-         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, true>), dim3(num_cells), dim3(64 * w), ldsPad, S(stream), a, w, sim->status);
-         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, true>), dim3(num_cells), dim3(64 * w), ldsPad, S(stream), a, w, sim->status);
+         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w, sim->status);
+         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w, sim->status);
       } else {
-         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, false>), dim3(num_cells), dim3(64 * w), ldsPad, S(stream), a, w, sim->status);
-         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, false>), dim3(num_cells), dim3(64 * w), ldsPad, S(stream), a, w, sim->status);
+         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w, sim->status);
+         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w, sim->status);
       }
    }
    LAUNCH_CHECK();

@@ -109,7 +109,8 @@ __global__ __launch_bounds__(256)
 void LJ_Force_thread_atom(LjArgs a, int wavesPerCell, int* __restrict__ status)
 {
    const int lane = threadIdx.x & 63;
-   const int gw = uniform(xcdRemap(blockIdx.x, gridDim.x) * wavesPerCell + (threadIdx.x >> 6));
+   // one workgroup per cell when wavesPerCell <= 4 (blockDim = 64 * wavesPerCell); otherwise 4-wave workgroups laid flat over (cell, chunk)
+   const int gw = uniform(xcdRemap(blockIdx.x, gridDim.x) * (blockDim.x >> 6) + (threadIdx.x >> 6));
    const int ci = gw / wavesPerCell;
    const int chunk = gw - ci * wavesPerCell;
    if (ci >= a.nCells) return;
