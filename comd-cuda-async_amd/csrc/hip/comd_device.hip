@@ -430,6 +430,16 @@ extern "C" void advancePositionGpu(SimGpu* sim, real_t dt)
    LAUNCH_CHECK();
 }
 
+extern "C" void advanceVelocityPositionGpu(SimGpu* sim, real_t dtKick, real_t dtDrift)
+{
+   const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
+   hipLaunchKernelGGL(AdvanceVelocityPosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
+                      sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.iSpecies, sim->species_mass,
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick, dtDrift);
+   LAUNCH_CHECK();
+}
+
 extern "C" void computeEnergy(SimGpu* sim, real_t* eLocal)
 {
    hipStream_t st = S(sim->boundary_stream);
@@ -461,6 +471,12 @@ static int sortBlock(int cap) { return ((cap + 63) / 64) * 64; }
 static void launchCompactSort(SimGpu* sim, int first, int nCells, hipStream_t st)
 {
    if (nCells <= 0) return;
+   if (sim->maxAtoms <= 64) {
+      hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4)), dim3(256), 0, st,
+                         atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, first, nCells, sim->maxAtoms);
+      LAUNCH_CHECK();
+      return;
+   }
    hipLaunchKernelGGL(CompactSortCells, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), (size_t)sortBlock(sim->maxAtoms) * sizeof(int), st,
                       atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, first, sim->maxAtoms);
    LAUNCH_CHECK();
@@ -485,6 +501,10 @@ extern "C" void sortAtomsGpu(SimGpu* sim, comdStream_t stream)
 }
 
 // ---- halo pack / unpack ------------------------------------------------------------------------------------------------
+// set by comdForceScansReady(1) after scanCellListsGpu has filled every offset array the force exchange will use
+static int g_forceScansReady = 0;
+extern "C" void comdForceScansReady(int on) { g_forceScansReady = on; }
+
 extern "C" void getAtomMsgSoAPtr(char* buffer, AtomMsgSoA* m, int n)
 {
    m->gid = (int*)(buffer + COMD_ATOM_MSG_HEADER);
@@ -518,10 +538,19 @@ extern "C" void unloadAtomsBufferToGpu(const char* msg_d, int nBuf, int maxAtoms
    LAUNCH_CHECK();
 }
 
+extern "C" void scanCellListsGpu(SimGpu* sim, int nLists, int** d_cellLists, const int* nCells, int** d_cellOffsets, comdStream_t stream)
+{
+   if (nLists < 1 || nLists > 12) { fprintf(stderr, "scanCellListsGpu: 1..12 lists per call\n"); exit(-1); }
+   ScanJobs jobs;
+   for (int i = 0; i < nLists; ++i) { jobs.list[i] = d_cellLists[i]; jobs.n[i] = nCells[i]; jobs.out[i] = d_cellOffsets[i]; }
+   hipLaunchKernelGGL(ScanCellCountsBatch, dim3(nLists), dim3(1024), 0, S(stream), sim->boxes.nAtoms, jobs);
+   LAUNCH_CHECK();
+}
+
 extern "C" void loadForceBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
 {
    hipStream_t st = S(stream);
-   hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
+   if (!g_forceScansReady) hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
    hipLaunchKernelGGL(LoadForceBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, gpu_buf, d_cellList, d_cellOffsets,
                       sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
    LAUNCH_CHECK();
@@ -530,7 +559,7 @@ extern "C" void loadForceBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellL
 extern "C" void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
 {
    hipStream_t st = S(stream);
-   hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
+   if (!g_forceScansReady) hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
    hipLaunchKernelGGL(UnloadForceBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, gpu_buf, d_cellList, d_cellOffsets,
                       sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
    LAUNCH_CHECK();

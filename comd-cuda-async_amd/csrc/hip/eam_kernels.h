@@ -100,7 +100,7 @@ void EAM_Force_embed(EamArgs a)
 // partial sums of TWO atoms at a time: v_permlane32_swap puts one atom in each half of the wave, DPP row ops finish (no LDS).
 #define EAM_CTA_THREADS 256
 #define EAM_CTA_WAVES   4
-#define EAM_CTA_MAXCAND 352                        // stencil atoms a wave can stage (FCC Cu at 80^3: 283 on average); sized for 3 workgroups per CU
+#define EAM_CTA_MAXCAND 384                        // stencil atoms a wave can stage (FCC Cu at 80^3: 256..365, mean 283); 3 workgroups per CU
 #define EAM_CTA_QUEUE   128
 
 // A cell whose 27-cell stencil holds more than EAM_CTA_MAXCAND atoms (small boxes have larger cells) is handled by the
@@ -155,18 +155,18 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int NV = (STEP == 1) ? 5 : 3;                   // values reduced per atom: f (3) [+ e, rhobar]
-   constexpr int NC = (STEP == 1) ? 3 : 4;                   // doubles staged per candidate: r (3) [+ F']
+   constexpr int NC = 3;                                     // doubles staged per candidate: r; pass 3 also keeps its global slot (int)
    const int nRhoPad = a.rho.n + 3, nPhiPad = (STEP == 1) ? a.phi.n + 3 : 0;
    double* sRho = (double*)ldsRaw;
    double* sPhi = sRho + nRhoPad;
    double* waveBase = sPhi + nPhiPad;
-   constexpr int perWaveDoubles = NC * EAM_CTA_MAXCAND + (2 * EAM_CTA_QUEUE * 2 + 64 * 4) / 8;
+   constexpr int perWaveDoubles = NC * EAM_CTA_MAXCAND + (STEP == 3 ? EAM_CTA_MAXCAND / 2 : 0) + (2 * EAM_CTA_QUEUE * 2 + 64 * 4) / 8;
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
    double* sx = waveBase + (size_t)wave * perWaveDoubles;
    double* sy = sx + EAM_CTA_MAXCAND;
    double* sz = sy + EAM_CTA_MAXCAND;
-   double* sdf = sz + EAM_CTA_MAXCAND;                       // pass 3 only (aliases the queue region in pass 1: not used there)
-   unsigned short* qBase = (unsigned short*)(sx + NC * EAM_CTA_MAXCAND);    // one pair queue per atom of a group: their work can interleave
+   int* sSlot = (int*)(sz + EAM_CTA_MAXCAND);               // pass 3 only: global slot of each candidate, to fetch F'_j for accepted pairs
+   unsigned short* qBase = (unsigned short*)(sx + NC * EAM_CTA_MAXCAND + (STEP == 3 ? EAM_CTA_MAXCAND / 2 : 0));   // one pair queue per atom of a group
    int* sOff = (int*)(qBase + 2 * EAM_CTA_QUEUE);           // [32] exclusive candidate offsets of the stencil cells
    int* sBox = sOff + 32;                                    // [32] their cell ids
 
@@ -180,7 +180,12 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
    const int cellsPerRound = 64 >> capShift;
    const int myK = lane >> capShift, myJ = lane & (a.cap - 1);
 
-   for (int ci = blockIdx.x * EAM_CTA_WAVES + wave; ci < a.nCells; ci += gridDim.x * EAM_CTA_WAVES) {
+   // XCD-aware persistent walk.  Workgroup b runs on XCD b % 8 (round-robin dispatch); give XCD x the contiguous cell range
+   // [x*N/8, (x+1)*N/8) and let its workgroups sweep that range side by side, 4 consecutive cells (one per wave) each,
+   // so the stencil planes they share stay in that XCD's 4 MiB L2 (before: 14-18x re-fetch of the positions, rocprof FETCH_SIZE).
+   const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = (gridDim.x + 7 - xcd) >> 3;
+   const int cellLo = (int)((long)a.nCells * xcd / 8), cellHi = (int)((long)a.nCells * (xcd + 1) / 8);
+   for (int ci = cellLo + lb * EAM_CTA_WAVES + wave; ci < cellHi; ci += nlb * EAM_CTA_WAVES) {
       const int iBox = uniform(a.cells ? a.cells[ci] : ci);
       const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
       // (1) candidate offsets, own cell first
@@ -200,8 +205,8 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
       // (2) stage positions [and F'] of the stencil cells, in groups of GROUP rounds with all loads in flight together
       constexpr int GROUP = 4;                      // 4 rounds x (3-4 loads) in flight; 7 rounds cost 60 more VGPRs and a wave per SIMD
       for (int k0 = 0; k0 < 27; k0 += GROUP * cellsPerRound) {
-         double vx[GROUP], vy[GROUP], vz[GROUP], vd[GROUP];
-         int dst[GROUP];
+         double vx[GROUP], vy[GROUP], vz[GROUP];
+         int dst[GROUP], src[GROUP];
 #pragma unroll
          for (int g = 0; g < GROUP; ++g) {
             const int k = k0 + g * cellsPerRound + myK;
@@ -211,7 +216,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
                if (myJ < n) {
                   const size_t o = (size_t)sBox[k] * a.cap + myJ;
                   vx[g] = a.rx[o]; vy[g] = a.ry[o]; vz[g] = a.rz[o];
-                  if (STEP == 3) vd[g] = a.dfEmbed[o];
+                  src[g] = (int)o;
                   dst[g] = off + myJ;
                }
             }
@@ -220,7 +225,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
          for (int g = 0; g < GROUP; ++g)
             if (dst[g] >= 0) {
                sx[dst[g]] = vx[g]; sy[dst[g]] = vy[g]; sz[dst[g]] = vz[g];
-               if (STEP == 3) sdf[dst[g]] = vd[g];
+               if (STEP == 3) sSlot[dst[g]] = src[g];
             }
       }
       __builtin_amdgcn_wave_barrier();
@@ -238,7 +243,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
             unsigned short* q = qBase + u * EAM_CTA_QUEUE;
             if (i < ni) {                                             // wave-uniform
                const double xi = sx[i], yi = sy[i], zi = sz[i];
-               const double dfi = (STEP == 3) ? sdf[i] : 0.0;
+               const double dfi = (STEP == 3) ? a.dfEmbed[(size_t)iBox * a.cap + i] : 0.0;
                int qn = 0;
                for (int t = 0; t < nTiles; ++t) {
                   {
@@ -262,7 +267,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
                      double rho, drho, dphi;
                      interpolate(rhoT, r, rho, drho);
                      if (STEP == 1) { double phi; interpolate(phiT, r, phi, dphi); part[u][3] += phi; part[u][4] += rho; }
-                     else           { dphi = (dfi + sdf[jj]) * drho; }
+                     else           { dphi = (dfi + a.dfEmbed[sSlot[jj]]) * drho; }
                      dphi *= ir;
                      part[u][0] -= dphi * dx; part[u][1] -= dphi * dy; part[u][2] -= dphi * dz;
                   }
@@ -289,6 +294,6 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 static inline size_t eamCtaLdsBytes(int step, int nRho, int nPhi)
 {
    size_t tables = (size_t)(nRho + 3 + (step == 1 ? nPhi + 3 : 0)) * 8;
-   size_t perWave = (size_t)(step == 1 ? 3 : 4) * EAM_CTA_MAXCAND * 8 + 2 * EAM_CTA_QUEUE * 2 + 64 * 4;
+   size_t perWave = (size_t)3 * EAM_CTA_MAXCAND * 8 + (step == 3 ? EAM_CTA_MAXCAND * 4 : 0) + 2 * EAM_CTA_QUEUE * 2 + 64 * 4;
    return tables + EAM_CTA_WAVES * perWave;
 }

@@ -37,6 +37,23 @@ void AdvancePosition(double* __restrict__ rx, double* __restrict__ ry, double* _
    rx[tid] += dt * px[tid] * invMass; ry[tid] += dt * py[tid] * invMass; rz[tid] += dt * pz[tid] * invMass;
 }
 
+// half kick followed by the drift in one pass (same operations, same order, as AdvanceVelocity then AdvancePosition)
+__global__ __launch_bounds__(256)
+void AdvanceVelocityPosition(double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
+                             double* __restrict__ px, double* __restrict__ py, double* __restrict__ pz,
+                             const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
+                             const int* __restrict__ iSpecies, const double* __restrict__ speciesMass,
+                             const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double dtKick, double dtDrift)
+{
+   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int c = (int)(tid / cap);
+   if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
+   const double invMass = 1.0 / speciesMass[iSpecies[tid]];
+   const double x = px[tid] + dtKick * fx[tid], y = py[tid] + dtKick * fy[tid], z = pz[tid] + dtKick * fz[tid];
+   px[tid] = x; py[tid] = y; pz[tid] = z;
+   rx[tid] += dtDrift * x * invMass; ry[tid] += dtDrift * y * invMass; rz[tid] += dtDrift * z * invMass;
+}
+
 // ---- energy: stage 1 = per-block partial sums in a fixed order, stage 2 = one block adds the partials --------
 __global__ __launch_bounds__(256)
 void ReduceEnergyPartial(const double* __restrict__ e, const double* __restrict__ px, const double* __restrict__ py,
@@ -149,6 +166,37 @@ void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__
    if (t == 0) { nAtoms[c] = live; dirty[c] = 0; }
 }
 
+// Same for cap <= 64: one WAVE per cell, four cells per workgroup, keys exchanged with v_readlane (no LDS, no barrier).
+__global__ __launch_bounds__(256)
+void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int first, int nCells, int cap)
+{
+   const int lane = threadIdx.x & 63;
+   const int idx = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+   if (idx >= nCells) return;
+   const int c = first + idx;
+   if (!uniform(dirty[c])) return;
+   int n = uniform(nAtoms[c]);
+   if (n > cap) n = cap;
+   const size_t o = (size_t)c * cap + lane;
+   int key = 0x7fffffff, spec = 0;
+   double x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
+   if (lane < n) {
+      const int g = at.gid[o];
+      if (g >= 0) { key = g; spec = at.spec[o]; x = at.rx[o]; y = at.ry[o]; z = at.rz[o]; px = at.px[o]; py = at.py[o]; pz = at.pz[o]; }
+   }
+   int rank = 0, live = 0;
+   for (int j = 0; j < n; ++j) {
+      const int kj = __builtin_amdgcn_readlane(key, j);
+      rank += (kj < key); live += (kj != 0x7fffffff);
+   }
+   if (key != 0x7fffffff) {
+      const size_t d = (size_t)c * cap + rank;
+      at.gid[d] = key; at.spec[d] = spec;
+      at.rx[d] = x; at.ry[d] = y; at.rz[d] = z; at.px[d] = px; at.py[d] = py; at.pz[d] = pz;
+   }
+   if (lane == 0) { nAtoms[c] = live; dirty[c] = 0; }
+}
+
 // ---- exclusive scan of nAtoms over a cell list (gpu_kernels.cu:357-407 fill + scan) ---------------------
 // single workgroup of 1024 threads; out[i] = sum_{k<i} nAtoms[list[k]], out[n] = total; also copied to *total.
 __global__ __launch_bounds__(1024)
@@ -176,6 +224,39 @@ void ScanCellCounts(const int* __restrict__ nAtoms, const int* __restrict__ list
       __syncthreads();
    }
    if (threadIdx.x == 0) { out[n] = sCarry; if (total) *total = sCarry; }
+}
+
+// several independent scans in one launch: workgroup b serves job b (the twelve send/receive lists of the force exchange)
+struct ScanJobs { const int* list[12]; int n[12]; int* out[12]; };
+
+__global__ __launch_bounds__(1024)
+void ScanCellCountsBatch(const int* __restrict__ nAtoms, ScanJobs jobs)
+{
+   __shared__ int sWave[16];
+   __shared__ int sCarry;
+   const int* __restrict__ list = jobs.list[blockIdx.x];
+   const int n = jobs.n[blockIdx.x];
+   int* __restrict__ out = jobs.out[blockIdx.x];
+   if (threadIdx.x == 0) sCarry = 0;
+   __syncthreads();
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   for (int base = 0; base < n; base += 1024) {
+      const int i = base + threadIdx.x;
+      const int v = i < n ? nAtoms[list[i]] : 0;
+      int incl = v;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+      if (lane == 63) sWave[wave] = incl;
+      __syncthreads();
+      int wavePrefix = 0;
+      for (int w = 0; w < wave; ++w) wavePrefix += sWave[w];
+      const int carry = sCarry;
+      if (i < n) out[i] = carry + wavePrefix + incl - v;
+      __syncthreads();
+      if (threadIdx.x == 1023) sCarry = carry + wavePrefix + incl;
+      __syncthreads();
+   }
+   if (threadIdx.x == 0) out[n] = sCarry;
 }
 
 // ---- atom halo message -----------------------------------------------------------------------------------

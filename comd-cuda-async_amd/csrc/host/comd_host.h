@@ -172,6 +172,7 @@ typedef struct ForceExchangeParmsSt {
    int nCells[6];
    int *sendCells[6], *recvCells[6];
    int *sendCellsGpu[6], *recvCellsGpu[6];
+   int *sendOffsetsGpu[6], *recvOffsetsGpu[6];   /* device, nCells + 1 each: filled by one batched scan per step */
    int* d_cellOffsets;
    int capacityAtoms;
 } ForceExchangeParms;
@@ -181,6 +182,7 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
 void destroyHaloExchange(HaloExchange** haloExchange);
 void haloExchange(HaloExchange* haloExchange, void* data);
 void exchangeData(HaloExchange* haloExchange, void* data, int iAxis);
+void prepareForceExchange(HaloExchange* forceExchange, struct SimFlatSt* sim);   /* one batched scan of all twelve cell lists */
 int* mkAtomCellList(LinkCell* boxes, enum HaloFaceOrder iFace, int nCells);
 int* mkForceSendCellList(LinkCell* boxes, int face, int nCells);
 int* mkForceRecvCellList(LinkCell* boxes, int face, int nCells);

@@ -147,9 +147,9 @@ static int loadForceBuffer(void* vparms, void* vdata, int face, char* buf)
 {
    ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
    SimFlat* s = (SimFlat*)vdata;
-   loadForceBufferFromGpu((real_t*)buf, parms->nCells[face], parms->sendCellsGpu[face], parms->d_cellOffsets, &s->gpu, s->gpu.boundary_stream);
+   loadForceBufferFromGpu((real_t*)buf, parms->nCells[face], parms->sendCellsGpu[face], parms->sendOffsetsGpu[face], &s->gpu, s->gpu.boundary_stream);
    if (getNRanks() == 1) return -1;
-   int n = comdReadDeviceInt(parms->d_cellOffsets + parms->nCells[face], s->gpu.boundary_stream);
+   int n = comdReadDeviceInt(parms->sendOffsetsGpu[face] + parms->nCells[face], s->gpu.boundary_stream);
    return n * (int)sizeof(real_t);
 }
 
@@ -158,7 +158,7 @@ static void unloadForceBuffer(void* vparms, void* vdata, int face, int bufSize, 
    ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
    SimFlat* s = (SimFlat*)vdata;
    (void)bufSize;       /* positional: the receive cells hold the same atoms, in gid order, as the sender's send cells */
-   unloadForceBufferToGpu((const real_t*)buf, parms->nCells[face], parms->recvCellsGpu[face], parms->d_cellOffsets, &s->gpu, s->gpu.boundary_stream);
+   unloadForceBufferToGpu((const real_t*)buf, parms->nCells[face], parms->recvCellsGpu[face], parms->recvOffsetsGpu[face], &s->gpu, s->gpu.boundary_stream);
 }
 
 static void destroyForceExchange(void* vparms)
@@ -167,6 +167,7 @@ static void destroyForceExchange(void* vparms)
    for (int f = 0; f < 6; ++f) {
       free(parms->sendCells[f]); free(parms->recvCells[f]);
       comdDeviceFree(parms->sendCellsGpu[f]); comdDeviceFree(parms->recvCellsGpu[f]);
+      comdDeviceFree(parms->sendOffsetsGpu[f]); comdDeviceFree(parms->recvOffsetsGpu[f]);
    }
    comdDeviceFree(parms->d_cellOffsets);
 }
@@ -197,6 +198,8 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
       for (int f = 0; f < 6; ++f) {
          parms->sendCellsGpu[f] = uploadInts(parms->sendCells[f], parms->nCells[f]);
          parms->recvCellsGpu[f] = uploadInts(parms->recvCells[f], parms->nCells[f]);
+         parms->sendOffsetsGpu[f] = (int*)comdDeviceMalloc((long)(parms->nCells[f] + 1) * sizeof(int));
+         parms->recvOffsetsGpu[f] = (int*)comdDeviceMalloc((long)(parms->nCells[f] + 1) * sizeof(int));
       }
       parms->d_cellOffsets = (int*)comdDeviceMalloc((long)(maxSize + 1) * sizeof(int));
       hh->sendBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->sendBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
@@ -216,6 +219,18 @@ void destroyHaloExchange(HaloExchange** pp)
    }
    free(hh);
    *pp = NULL;
+}
+
+/* Occupancies are final once the atom exchange has been sorted: scan all twelve force-exchange cell lists in one launch. */
+void prepareForceExchange(HaloExchange* hh, SimFlat* sim)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)hh->parms;
+   int* lists[12]; int* offs[12]; int n[12];
+   for (int f = 0; f < 6; ++f) {
+      lists[f] = parms->sendCellsGpu[f];     offs[f] = parms->sendOffsetsGpu[f];     n[f] = parms->nCells[f];
+      lists[6 + f] = parms->recvCellsGpu[f]; offs[6 + f] = parms->recvOffsetsGpu[f]; n[6 + f] = parms->nCells[f];
+   }
+   scanCellListsGpu(&sim->gpu, 12, lists, n, offs, sim->gpu.boundary_stream);
 }
 
 /* ---- driver -------------------------------------------------------------------------------------------------- */

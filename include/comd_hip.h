@@ -184,6 +184,9 @@ void updateNeighborsGpuAsync(SimGpu* sim, int* temp, int nCells, int* cellList, 
 void advanceVelocityGpu(SimGpu* sim, real_t dt);
 /* advancePositionGpu(SimGpu*, dt), gpu_kernels.cu:336-349 */
 void advancePositionGpu(SimGpu* sim, real_t dt);
+/* the first half kick and the drift of a step in one pass over the atoms: bit-identical to advanceVelocityGpu(dtKick)
+ * followed by advancePositionGpu(dtDrift) (timestep.c:52-58), one launch and one sweep over p fewer */
+void advanceVelocityPositionGpu(SimGpu* sim, real_t dtKick, real_t dtDrift);
 /* computeEnergy(SimFlat*, real_t eLocal[2]), gpu_kernels.cu:1045-1059: {sum e, sum p^2/2m} of local atoms.
  * Deterministic two-stage reduction (the reference uses fp64 atomics). Blocks until the result is on the host. */
 void computeEnergy(SimGpu* sim, real_t* eLocal);
@@ -227,6 +230,11 @@ void unloadAtomsBufferToGpu(const char* msg_d, int nBuf, int maxAtomsInMsg, SimG
 void loadForceBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream);
 /* unloadForceBufferToGpu(buf, nBuf, nCells, cellList, natoms_buf, partial_sums, SimFlat*, gpu_buf, stream), :642-660 */
 void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream);
+/* The force exchange scans twelve cell lists per step (natoms_buf/partial_sums of haloExchange.c:438-465).  Occupancies are final
+ * once the atom exchange has been sorted, so all of them can be scanned in ONE launch: scanCellListsGpu fills d_cellOffsets[i]
+ * (nCells[i] + 1 ints) for up to 12 lists; comdForceScansReady(1) then tells load/unloadForceBuffer*Gpu to use those offsets as they are. */
+void scanCellListsGpu(SimGpu* sim, int nLists, int** d_cellLists, const int* nCells, int** d_cellOffsets, comdStream_t stream);
+void comdForceScansReady(int on);
 /* blocking read of one device int (message counts for the multi-rank transport) */
 int  comdReadDeviceInt(const int* d_ptr, comdStream_t stream);
 
