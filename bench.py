@@ -31,6 +31,10 @@ HBM_PEAK_GBS = 8000.0
 FORCE_BYTES = {"lj": 56.0, "eam": 176.0}        # algorithmic bytes per atom per force evaluation
 STEP_BYTES = {"lj": 276.0, "eam": 396.0}        # ... per full time step (force + 2 half kicks + drift)
 GRIDS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
+# fp64 vector ceiling (the bound that actually binds these kernels): useful FLOP per atom per force evaluation.
+# LJ 5 sigma: ~4000 candidates x (3 sub + mul + 2 fma = 8 FLOP) + ~550 pairs x ~25 FLOP; EAM: 2 passes x (~283 x 8 + ~42 x ~70).
+FP64_VECTOR_PEAK_TFLOPS = 78.6
+FORCE_FLOP = {"lj": 4000 * 8 + 550 * 25, "eam": 2 * (283 * 8 + 42 * 70)}
 
 
 def parse():
@@ -68,6 +72,19 @@ def cpu_baseline(pot, seconds):
     rate = o.n_global * steps / loop
     return {"value": rate, "unit": "atom-updates/s", "cores": int(lib.oracle_threads()), "kind": "port",
             "sample": f"{pot.upper()} Cu {n}^3 FCC ({o.n_global} atoms), {steps} steps, oracle/comd_oracle.c (27-cell stencil form, OpenMP), {loop:.1f} s"}
+
+
+def measured_traffic(pot, method, nx):
+    """HBM-side bytes per force evaluation from the committed rocprofv3 PMC passes (profiles/r01_traffic.json), or None.
+    PMC counters cannot be read from inside the timed process, so the last profiled value for this workload is reported."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        rec = json.load(open(path)).get(f"{pot}/{method}/{nx}")
+    except (OSError, ValueError):
+        return None
+    if not rec:
+        return None
+    return (rec["fetch_KiB"] + rec["write_KiB"]) * 1024.0
 
 
 def main():
@@ -152,11 +169,15 @@ def main():
             "per_gpu_value": value / a.gpus,
             "energy_per_atom_eV": (ep + ek) / n_global,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": None,
+                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+                         "traffic": measured_traffic(a.pot, method, a.nx) if a.gpus == 1 else None,
                          "kernel": ("LJ_Force_" if a.pot == "lj" else "EAM_Force_") + method,
                          "kernel_ms_per_step": force_per_step_ms, "launches_timed": int(n_launch.value),
                          "algorithmic_bytes_per_atom": FORCE_BYTES[a.pot],
                          "whole_step_achieved_GBs": STEP_BYTES[a.pot] * value / a.gpus / 1e9,
+                         "fp64_vector": {"achieved_TFLOPs": FORCE_FLOP[a.pot] * n_local / (force_per_step_ms * 1e-3) / 1e12 if force_ms > 0 else None,
+                                         "peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "flop_per_atom": FORCE_FLOP[a.pot],
+                                         "frac": FORCE_FLOP[a.pot] * n_local / (force_per_step_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if force_ms > 0 else None},
                          "note": "fp64 ALU-bound stencil: ~4000 (LJ) / ~283 (EAM) candidate pairs per atom against 56 / 176 algorithmic bytes (SURVEY.md 8d)"},
         }
         if a.gpus == 1 and not a.no_cpu_baseline:

@@ -118,25 +118,61 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell, int* __restrict__ status)
    const int ni = uniform(a.nAtoms[iBox]);
    if (chunk * 64 >= ni) return;
 
-   const int iSlot = chunk * 64 + lane;
-   const bool active = iSlot < ni;
-   const size_t iOff = (size_t)iBox * a.cap + (active ? iSlot : ni - 1);   // idle lanes shadow the last atom
-   const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
-   double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
-
+   const int m = uniform(ni - chunk * 64 < 64 ? ni - chunk * 64 : 64);     // atoms this wave owns
    const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
-   if (PIPE) {
-      ljCellLoopPipelined<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
-      for (int k = 1; k < 27; ++k) ljCellLoopPipelined<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
-   } else {
-      ljCellLoop<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
-      for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
-   }
+   const double fs = 24.0 * a.eps;
 
-   if (active) {
-      const double fs = 24.0 * a.eps;
-      a.fx[iOff] = fx * fs; a.fy[iOff] = fy * fs; a.fz[iOff] = fz * fs;
-      if (ENERGY) a.e[iOff] = e * 2.0 * a.eps;          // 4 eps * 1/2 per pair
+   if (m <= 32) {
+      // Under-filled wave (the tail of a cell: 20 of 64 lanes for 148 atoms).  Replicate its atoms G = 64/m times across the lanes
+      // and give replica g the stencil cells k = g, g+G, g+2G, ...: the wave finishes in ~1/G of the neighbour iterations.  The
+      // neighbour is no longer wave-uniform here, so positions come through per-lane loads; replicas are summed with ds_bpermute.
+      const int G = uniform(64 / m < 4 ? 64 / m : 4);
+      const int g = lane / m, ai = lane - g * m;
+      const bool valid = g < G;
+      const size_t iOff = (size_t)iBox * a.cap + chunk * 64 + (valid ? ai : 0);
+      const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+      double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+      for (int t = 0; t * G < 27; ++t) {
+         const int k = t * G + g;
+         const bool okk = valid && k < 27;
+         const int jBox = okk ? nb[k] : iBox;
+         const int nj = okk ? a.nAtoms[jBox] : 0;
+         const size_t base = (size_t)jBox * a.cap;
+         for (int j = 0; __any(j < nj); ++j) {
+            if (j < nj) {
+               const double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
+               const double r2 = dx*dx + dy*dy + dz*dz;
+               if (r2 <= a.rc2 && r2 > 0.0) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+            }
+         }
+      }
+      double tx = fx, ty = fy, tz = fz, te = e;
+      for (int r = 1; r < G; ++r) {                       // all lanes take part; only lanes < m keep the result
+         const int src = (ai + r * m) & 63;
+         tx += bpermute64(fx, src); ty += bpermute64(fy, src); tz += bpermute64(fz, src);
+         if (ENERGY) te += bpermute64(e, src);
+      }
+      if (lane < m) {
+         a.fx[iOff] = tx * fs; a.fy[iOff] = ty * fs; a.fz[iOff] = tz * fs;
+         if (ENERGY) a.e[iOff] = te * 2.0 * a.eps;
+      }
+   } else {
+      const int iSlot = chunk * 64 + lane;
+      const bool active = iSlot < ni;
+      const size_t iOff = (size_t)iBox * a.cap + (active ? iSlot : ni - 1);   // idle lanes shadow the last atom
+      const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+      double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+      if (PIPE) {
+         ljCellLoopPipelined<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
+         for (int k = 1; k < 27; ++k) ljCellLoopPipelined<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
+      } else {
+         ljCellLoop<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
+         for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
+      }
+      if (active) {
+         a.fx[iOff] = fx * fs; a.fy[iOff] = fy * fs; a.fz[iOff] = fz * fs;
+         if (ENERGY) a.e[iOff] = e * 2.0 * a.eps;          // 4 eps * 1/2 per pair
+      }
    }
    // NOTE: every store/atomic of this kernel sits below its last load.  A store above the neighbour loop makes the compiler
    // give up proving the position arrays unclobbered and it silently replaces the s_load_dwordx16 stream by per-lane
