@@ -64,7 +64,7 @@ def cpu_baseline(pot, seconds):
     o = orc.Oracle(n, eam=1 if pot == "eam" else 0)
     o.step(2)
     per_step = max((time.time() - t0) / 3.0, 1e-4)
-    steps = max(5, min(200, int(seconds / per_step)))
+    steps = max(5, min(2000, int(seconds / per_step)))
     lib = orc.lib()
     before = lib.oracle_loop_seconds(o.ptr)
     o.step(steps)

@@ -270,7 +270,6 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
       fprintf(stderr, "Rank %d, GPU: %d, %s: ", g_rank, sim->deviceId, where);
       if (st[0] & 1) fprintf(stderr, "a link cell overflowed its %d slots (raise --maxAtoms); ", sim->maxAtoms);
       if (st[0] & 2) fprintf(stderr, "a cell stencil holds more atoms than the cta_cell kernel can stage; ");
-      if (st[0] & 4) fprintf(stderr, "a cell outgrew SimGpu.max_atoms_cell + 16 between two occupancy refreshes (sumAtoms); ");
       if (st[1])     fprintf(stderr, "an atom moved beyond the halo region and was lost; ");
       if (st[2])     fprintf(stderr, "a halo message overflowed its buffer; ");
       fprintf(stderr, "\n");
@@ -325,8 +324,11 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       // Measured on MI355X (LJ 80^3): workgroup = cap/64 = 4 waves per cell with the tail wave exiting at once runs the kernel in
       // 4.73 ms; sizing the workgroup to the 3 live waves (max_atoms_cell) 6.05 ms; single-wave workgroups 5.64 ms.  The waves of one
       // cell walk the same neighbour data in step (shared scalar-cache lines), and fewer, wider workgroups keep that locality.
+      // waves per cell: sized to the occupancy the host last saw (+16 atoms of slack), never more than cap/64.  Cells that outgrow the
+      // estimate stay correct (their waves take extra chunks).  COMD_LJ_WAVES=k forces k (tests use 1 to exercise the extra-chunk path).
       int w = sim->maxAtoms / 64;
-      { const char* e = getenv("COMD_LJ_WAVES"); if (!(e && atoi(e) == 0) && sim->max_atoms_cell > 0) { w = (sim->max_atoms_cell + 16 + 63) / 64; if (w > sim->maxAtoms / 64) w = sim->maxAtoms / 64; } }
+      if (sim->max_atoms_cell > 0 && (sim->max_atoms_cell + 16 + 63) / 64 < w) w = (sim->max_atoms_cell + 16 + 63) / 64;
+      { const char* e = getenv("COMD_LJ_WAVES"); if (e && atoi(e) > 0 && atoi(e) < w) w = atoi(e); }
       const int wavesPerBlock = w <= 4 ? w : 4;
       const unsigned nBlocks = w <= 4 ? (unsigned)num_cells : (unsigned)ceilDiv((long)num_cells * w, 4);
       static int ldsPad = -1;
@@ -334,11 +336,11 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       static int pipe = -1;
       if (pipe < 0) { const char* e = getenv("COMD_LJ_PIPE"); pipe = e ? atoi(e) : 0; }
       if (pipe) {
-         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w, sim->status);
-         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w, sim->status);
+         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w);
+         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w);
       } else {
-         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w, sim->status);
-         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w, sim->status);
+         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w);
+         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w);
       }
    }
    LAUNCH_CHECK();

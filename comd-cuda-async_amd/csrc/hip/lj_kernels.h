@@ -100,13 +100,57 @@ __device__ __forceinline__ void ljCellLoopPipelined(const LjArgs& a, int jBox, d
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Generic chunk: the wave owns m <= 64 atoms (slots chunk*64 .. chunk*64+m-1 of iBox).  With m <= 32 the atoms are replicated
+// G = 64/m (<= 4) times across the lanes and replica g takes the stencil cells k = g, g+G, g+2G, ..., so the wave finishes in
+// ~1/G of the neighbour iterations; replicas are summed with ds_bpermute.  The neighbour is not wave-uniform here, so
+// positions come through per-lane loads.  Used for the under-filled tail wave of a cell (20 of 64 lanes for 148 atoms)
+// and for chunks beyond the host's occupancy estimate.
+template <bool ENERGY>
+__device__ __forceinline__ void ljChunkGeneric(const LjArgs& a, int iBox, int ni, int chunk, int lane)
+{
+   const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
+   const int m = ni - chunk * 64 < 64 ? ni - chunk * 64 : 64;
+   const int G = 64 / m < 4 ? 64 / m : 4;
+   const int g = lane / m, ai = lane - g * m;
+   const bool valid = g < G;
+   const size_t iOff = (size_t)iBox * a.cap + chunk * 64 + (valid ? ai : 0);
+   const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+   double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+   for (int t = 0; t * G < 27; ++t) {
+      const int k = t * G + g;
+      const bool okk = valid && k < 27;
+      const int jBox = okk ? nb[k] : iBox;
+      const int nj = okk ? a.nAtoms[jBox] : 0;
+      const size_t base = (size_t)jBox * a.cap;
+      for (int j = 0; __any(j < nj); ++j) {
+         if (j < nj) {
+            const double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
+            const double r2 = dx*dx + dy*dy + dz*dz;
+            if (r2 <= a.rc2 && r2 > 0.0) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+         }
+      }
+   }
+   double tx = fx, ty = fy, tz = fz, te = e;
+   for (int r = 1; r < G; ++r) {                       // all lanes take part; only lanes < m keep the result
+      const int src = (ai + r * m) & 63;
+      tx += bpermute64(fx, src); ty += bpermute64(fy, src); tz += bpermute64(fz, src);
+      if (ENERGY) te += bpermute64(e, src);
+   }
+   if (lane < m) {
+      const double fs = 24.0 * a.eps;
+      a.fx[iOff] = tx * fs; a.fy[iOff] = ty * fs; a.fz[iOff] = tz * fs;
+      if (ENERGY) a.e[iOff] = te * 2.0 * a.eps;
+   }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // thread per atom, wave per 64-slot chunk of a cell.  Requires cap % 64 == 0.
 // grid: one workgroup of `wavesPerCell` waves per cell, where wavesPerCell = ceil((largest occupancy + slack) / 64) as
 // last seen by the host (SimGpu.max_atoms_cell) -- 3 waves for 5-sigma LJ Cu instead of cap/64 = 4, so no wave is born dead.
-// A cell that outgrew that bound raises status bit 4 (checked with the other flags at the next energy read).
+// A cell that outgrew that estimate is still complete: its waves take the extra chunks through the generic path.
 template <bool ENERGY, bool PIPE>
 __global__ __launch_bounds__(256)
-void LJ_Force_thread_atom(LjArgs a, int wavesPerCell, int* __restrict__ status)
+void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
 {
    const int lane = threadIdx.x & 63;
    // one workgroup per cell when wavesPerCell <= 4 (blockDim = 64 * wavesPerCell); otherwise 4-wave workgroups laid flat over (cell, chunk)
@@ -117,46 +161,13 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell, int* __restrict__ status)
    const int iBox = uniform(a.cells ? a.cells[ci] : ci);
    const int ni = uniform(a.nAtoms[iBox]);
    if (chunk * 64 >= ni) return;
-
    const int m = uniform(ni - chunk * 64 < 64 ? ni - chunk * 64 : 64);     // atoms this wave owns
-   const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
-   const double fs = 24.0 * a.eps;
 
    if (m <= 32) {
-      // Under-filled wave (the tail of a cell: 20 of 64 lanes for 148 atoms).  Replicate its atoms G = 64/m times across the lanes
-      // and give replica g the stencil cells k = g, g+G, g+2G, ...: the wave finishes in ~1/G of the neighbour iterations.  The
-      // neighbour is no longer wave-uniform here, so positions come through per-lane loads; replicas are summed with ds_bpermute.
-      const int G = uniform(64 / m < 4 ? 64 / m : 4);
-      const int g = lane / m, ai = lane - g * m;
-      const bool valid = g < G;
-      const size_t iOff = (size_t)iBox * a.cap + chunk * 64 + (valid ? ai : 0);
-      const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
-      double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
-      for (int t = 0; t * G < 27; ++t) {
-         const int k = t * G + g;
-         const bool okk = valid && k < 27;
-         const int jBox = okk ? nb[k] : iBox;
-         const int nj = okk ? a.nAtoms[jBox] : 0;
-         const size_t base = (size_t)jBox * a.cap;
-         for (int j = 0; __any(j < nj); ++j) {
-            if (j < nj) {
-               const double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
-               const double r2 = dx*dx + dy*dy + dz*dz;
-               if (r2 <= a.rc2 && r2 > 0.0) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
-            }
-         }
-      }
-      double tx = fx, ty = fy, tz = fz, te = e;
-      for (int r = 1; r < G; ++r) {                       // all lanes take part; only lanes < m keep the result
-         const int src = (ai + r * m) & 63;
-         tx += bpermute64(fx, src); ty += bpermute64(fy, src); tz += bpermute64(fz, src);
-         if (ENERGY) te += bpermute64(e, src);
-      }
-      if (lane < m) {
-         a.fx[iOff] = tx * fs; a.fy[iOff] = ty * fs; a.fz[iOff] = tz * fs;
-         if (ENERGY) a.e[iOff] = te * 2.0 * a.eps;
-      }
+      ljChunkGeneric<ENERGY>(a, iBox, ni, chunk, lane);
    } else {
+      // full wave: neighbour j is wave-uniform -> positions arrive through the scalar unit
+      const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
       const int iSlot = chunk * 64 + lane;
       const bool active = iSlot < ni;
       const size_t iOff = (size_t)iBox * a.cap + (active ? iSlot : ni - 1);   // idle lanes shadow the last atom
@@ -170,14 +181,15 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell, int* __restrict__ status)
          for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
       }
       if (active) {
+         const double fs = 24.0 * a.eps;
          a.fx[iOff] = fx * fs; a.fy[iOff] = fy * fs; a.fz[iOff] = fz * fs;
          if (ENERGY) a.e[iOff] = e * 2.0 * a.eps;          // 4 eps * 1/2 per pair
       }
    }
-   // NOTE: every store/atomic of this kernel sits below its last load.  A store above the neighbour loop makes the compiler
-   // give up proving the position arrays unclobbered and it silently replaces the s_load_dwordx16 stream by per-lane
-   // global_load (measured: 4.7 ms -> 6.2 ms).
-   if (ni > wavesPerCell * 64 && chunk == 0 && lane == 0) atomicOr(&status[0], 4);
+   // NOTE: no store may precede the scalar-path loads above on any path through this kernel, or the compiler gives up proving the
+   // position arrays unclobbered and silently replaces the s_load_dwordx16 stream by per-lane global_load (measured: 4.7 -> 6.2 ms).
+   // Everything below runs after the wave's first chunk is stored.  Check `grep -c s_load_dwordx16` in the ISA after edits here.
+   for (int c = chunk + wavesPerCell; c * 64 < ni; c += wavesPerCell) ljChunkGeneric<ENERGY>(a, iBox, ni, c, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------

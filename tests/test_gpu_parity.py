@@ -46,6 +46,19 @@ def test_forces_match_oracle(gpu, orc, method, eam, n, delta):
             assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < 1e-12
 
 
+def test_lj_cells_larger_than_the_launch_estimate(gpu, orc, monkeypatch):
+    """thread_atom sizes its workgroups from the host's last occupancy reading; a cell that outgrew it must still be complete.
+    Forcing one wave per cell makes every cell take the extra-chunk path (chunks 1 and 2 through the generic per-lane code)."""
+    monkeypatch.setenv("COMD_LJ_WAVES", "1")
+    with gpu.Simulation(_args(10, 0, 0.1, "thread_atom")) as sim:
+        o = orc.Oracle(10, eam=0, delta=0.1)
+        sim.step(3)
+        o.step(3)
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= 1e-10 * np.abs(fo).max()
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+
+
 @pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("case", ["eam_6_delta", "lj_8_delta"])
 def test_reference_recorded_forces(gpu, case, method):
