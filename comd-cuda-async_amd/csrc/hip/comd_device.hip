@@ -331,17 +331,8 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       { const char* e = getenv("COMD_LJ_WAVES"); if (e && atoi(e) > 0 && atoi(e) < w) w = atoi(e); }
       const int wavesPerBlock = w <= 4 ? w : 4;
       const unsigned nBlocks = w <= 4 ? (unsigned)num_cells : (unsigned)ceilDiv((long)num_cells * w, 4);
-      static int ldsPad = -1;
-      if (ldsPad < 0) { const char* e = getenv("COMD_LJ_LDS"); ldsPad = e ? atoi(e) : 0; }
-      static int pipe = -1;
-      if (pipe < 0) { const char* e = getenv("COMD_LJ_PIPE"); pipe = e ? atoi(e) : 0; }
-      if (pipe) {
-         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w);
-         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w);
-      } else {
-         if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w);
-         else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), ldsPad, S(stream), a, w);
-      }
+      if (g_needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom<true>, dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w);
+      else              hipLaunchKernelGGL(LJ_Force_thread_atom<false>, dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w);
    }
    LAUNCH_CHECK();
 }

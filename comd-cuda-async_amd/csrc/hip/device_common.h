@@ -136,6 +136,31 @@ __device__ __forceinline__ void interpolate(const TableView& t, double r, double
    df = (g1 + r * (g2 - g1)) * t.invDxHalf;
 }
 
+// phi(r) and rho(r) tabulated on the SAME grid (funcfl files are): values interleaved {phi_i, rho_i} so one index
+// computation and four 16-byte LDS reads serve both interpolations.  v[2*i], v[2*i+1]; i = 0 is the leading pad.
+__device__ __forceinline__ void interpolatePair(const double* __restrict__ v, const TableView& t, double r,
+                                                double& phi, double& dphi, double& rho, double& drho)
+{
+   r = fmax(r, t.x0);
+   r = fmin(r, t.xn);
+   r = r * t.invDx - t.invDxXx0;
+   const double ri = floor(r);
+   const int ii = (int)ri;
+   r -= ri;
+   const double2* __restrict__ q = reinterpret_cast<const double2*>(v) + ii;
+   const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+   {
+      const double g1 = a2.x - a0.x, g2 = a3.x - a1.x;
+      phi  = a1.x + 0.5 * r * (g1 + r * (a2.x + a0.x - 2.0 * a1.x));
+      dphi = (g1 + r * (g2 - g1)) * t.invDxHalf;
+   }
+   {
+      const double g1 = a2.y - a0.y, g2 = a3.y - a1.y;
+      rho  = a1.y + 0.5 * r * (g1 + r * (a2.y + a0.y - 2.0 * a1.y));
+      drho = (g1 + r * (g2 - g1)) * t.invDxHalf;
+   }
+}
+
 __device__ __forceinline__ CellGeom makeGeom(const LinkCellGpu& b)
 {
    CellGeom c;

@@ -106,7 +106,7 @@ void EAM_Force_embed(EamArgs a)
 // A cell whose 27-cell stencil holds more than EAM_CTA_MAXCAND atoms (small boxes have larger cells) is handled by the
 // same wave in the thread-per-atom form: lane = i atom, neighbours streamed from global memory, tables still in LDS.
 template <int STEP>
-__device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int lane, const TableView& rhoT, const TableView& phiT)
+__device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int lane, const TableView& rhoT, const TableView& phiT, bool sameGrid)
 {
    const int ni = a.nAtoms[iBox];
    const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
@@ -125,9 +125,15 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
             if (r2 <= a.rc2 && r2 > 0.0) {
                const double ir = rsqrt64(r2), r = r2 * ir;
                double rho, drho, dphi;
-               interpolate(rhoT, r, rho, drho);
-               if (STEP == 1) { double phi; interpolate(phiT, r, phi, dphi); e += phi; rb += rho; }
-               else           { dphi = (dfi + a.dfEmbed[base + j]) * drho; }
+               if (STEP == 1) {
+                  double phi;
+                  if (sameGrid) interpolatePair(rhoT.v, rhoT, r, phi, dphi, rho, drho);
+                  else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
+                  e += phi; rb += rho;
+               } else {
+                  interpolate(rhoT, r, rho, drho);
+                  dphi = (dfi + a.dfEmbed[base + j]) * drho;
+               }
                dphi *= ir;
                fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
             }
@@ -170,8 +176,14 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
    int* sOff = (int*)(qBase + 2 * EAM_CTA_QUEUE);           // [32] exclusive candidate offsets of the stencil cells
    int* sBox = sOff + 32;                                    // [32] their cell ids
 
-   for (int t = threadIdx.x; t < nRhoPad; t += EAM_CTA_THREADS) sRho[t] = a.rho.values[t];
-   if (STEP == 1) for (int t = threadIdx.x; t < nPhiPad; t += EAM_CTA_THREADS) sPhi[t] = a.phi.values[t];
+   // pass 1 on a shared r grid (funcfl): one interleaved {phi, rho} table; otherwise two separate tables
+   const bool sameGrid = (STEP == 1) && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+   if (sameGrid) {
+      for (int t = threadIdx.x; t < nRhoPad; t += EAM_CTA_THREADS) { sRho[2 * t] = a.phi.values[t]; sRho[2 * t + 1] = a.rho.values[t]; }
+   } else {
+      for (int t = threadIdx.x; t < nRhoPad; t += EAM_CTA_THREADS) sRho[t] = a.rho.values[t];
+      if (STEP == 1) for (int t = threadIdx.x; t < nPhiPad; t += EAM_CTA_THREADS) sPhi[t] = a.phi.values[t];
+   }
    __syncthreads();
    const TableView rhoT = makeTable(a.rho, sRho), phiT = makeTable(a.phi, sPhi);
 
@@ -200,7 +212,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
       __builtin_amdgcn_wave_barrier();
       const int nCand = uniform(sOff[27]);
       const int ni = uniform(sOff[1]);
-      if (nCand > EAM_CTA_MAXCAND) { eamCellDirect<STEP>(a, iBox, lane, rhoT, phiT); continue; }
+      if (nCand > EAM_CTA_MAXCAND) { eamCellDirect<STEP>(a, iBox, lane, rhoT, phiT, sameGrid); continue; }
 
       // (2) stage positions [and F'] of the stencil cells, in groups of GROUP rounds with all loads in flight together
       constexpr int GROUP = 4;                      // 4 rounds x (3-4 loads) in flight; 7 rounds cost 60 more VGPRs and a wave per SIMD
@@ -265,9 +277,15 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
                      const double r2 = dx*dx + dy*dy + dz*dz;
                      const double ir = rsqrt64(r2), r = r2 * ir;
                      double rho, drho, dphi;
-                     interpolate(rhoT, r, rho, drho);
-                     if (STEP == 1) { double phi; interpolate(phiT, r, phi, dphi); part[u][3] += phi; part[u][4] += rho; }
-                     else           { dphi = (dfi + a.dfEmbed[sSlot[jj]]) * drho; }
+                     if (STEP == 1) {
+                        double phi;
+                        if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
+                        else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
+                        part[u][3] += phi; part[u][4] += rho;
+                     } else {
+                        interpolate(rhoT, r, rho, drho);
+                        dphi = (dfi + a.dfEmbed[sSlot[jj]]) * drho;
+                     }
                      dphi *= ir;
                      part[u][0] -= dphi * dx; part[u][1] -= dphi * dy; part[u][2] -= dphi * dz;
                   }

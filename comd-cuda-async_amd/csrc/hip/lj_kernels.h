@@ -71,34 +71,6 @@ __device__ __forceinline__ void ljCellLoop(const LjArgs& a, int jBox, double xi,
    }
 }
 
-// same, software pipelined: the scalar loads of batch b+1 (4 neighbours) are issued before batch b is evaluated
-template <bool SELF, bool ENERGY>
-__device__ __forceinline__ void ljCellLoopPipelined(const LjArgs& a, int jBox, double xi, double yi, double zi,
-                                                    double& fx, double& fy, double& fz, double& e)
-{
-   const int nj = uniform(a.nAtoms[jBox]);
-   const double* __restrict__ px = a.rx + (size_t)jBox * a.cap;
-   const double* __restrict__ py = a.ry + (size_t)jBox * a.cap;
-   const double* __restrict__ pz = a.rz + (size_t)jBox * a.cap;
-   // the slot arrays are padded to cap >= nj rounded up to 4 (cap % 64 == 0), so reading one batch past nj is in bounds
-   double xs[4], ys[4], zs[4], xn[4], yn[4], zn[4];
-#pragma unroll
-   for (int u = 0; u < 4; ++u) { xs[u] = px[u]; ys[u] = py[u]; zs[u] = pz[u]; }
-   for (int j = 0; j < nj; j += 4) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { xn[u] = px[j + 4 + u]; yn[u] = py[j + 4 + u]; zn[u] = pz[j + 4 + u]; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-         double dx = xi - xs[u], dy = yi - ys[u], dz = zi - zs[u];
-         double r2 = dx*dx + dy*dy + dz*dz;
-         bool hit = (SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2)) && (j + u < nj);
-         if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { xs[u] = xn[u]; ys[u] = yn[u]; zs[u] = zn[u]; }
-   }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // Generic chunk: the wave owns m <= 64 atoms (slots chunk*64 .. chunk*64+m-1 of iBox).  With m <= 32 the atoms are replicated
 // G = 64/m (<= 4) times across the lanes and replica g takes the stencil cells k = g, g+G, g+2G, ..., so the wave finishes in
@@ -148,7 +120,7 @@ __device__ __forceinline__ void ljChunkGeneric(const LjArgs& a, int iBox, int ni
 // grid: one workgroup of `wavesPerCell` waves per cell, where wavesPerCell = ceil((largest occupancy + slack) / 64) as
 // last seen by the host (SimGpu.max_atoms_cell) -- 3 waves for 5-sigma LJ Cu instead of cap/64 = 4, so no wave is born dead.
 // A cell that outgrew that estimate is still complete: its waves take the extra chunks through the generic path.
-template <bool ENERGY, bool PIPE>
+template <bool ENERGY>
 __global__ __launch_bounds__(256)
 void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
 {
@@ -173,13 +145,10 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
       const size_t iOff = (size_t)iBox * a.cap + (active ? iSlot : ni - 1);   // idle lanes shadow the last atom
       const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
       double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
-      if (PIPE) {
-         ljCellLoopPipelined<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
-         for (int k = 1; k < 27; ++k) ljCellLoopPipelined<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
-      } else {
-         ljCellLoop<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
-         for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
-      }
+      // (a software-pipelined variant -- scalar loads of batch b+1 issued before batch b is evaluated, 4 neighbours per batch to fit
+      // two batches in SGPRs -- measured 9 % slower: 4.30 vs 3.95 ms; the 8-wide batches below rely on the other waves for latency cover)
+      ljCellLoop<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
+      for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
       if (active) {
          const double fs = 24.0 * a.eps;
          a.fx[iOff] = fx * fs; a.fy[iOff] = fy * fs; a.fz[iOff] = fz * fs;

@@ -129,3 +129,22 @@ def test_product_never_links_the_oracle():
                 assert "liboracle" not in text and "comd_oracle" not in text and "oracle_binding" not in text, f
     out = subprocess.run(["ldd", os.path.join(pkg_dir, "csrc", "libcomd_host.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_lj_thread_atom_keeps_its_scalar_load_stream(tmp_path):
+    """The LJ thread_atom kernel is fast because the neighbour positions arrive through s_load_dwordx16 (wave-uniform j).
+    A store ahead of those loads makes hipcc fall back to per-lane global_load without a word (4.7 -> 6.2 ms on MI355X);
+    pin the ISA: the full-wave path must keep its scalar loads."""
+    import shutil
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    src = os.path.join(ROOT, "comd-cuda-async_amd", "csrc", "hip", "comd_device.hip")
+    out = tmp_path / "dev.s"
+    proc = subprocess.run(["hipcc", "-O3", "--offload-arch=gfx950", "-std=c++17", "-Wno-comment", "-I" + os.path.join(ROOT, "include"),
+                           "-I" + os.path.dirname(src), "-S", "--cuda-device-only", "-o", str(out), src], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    text = out.read_text()
+    kernels = re.findall(r"^(_Z20LJ_Force_thread_atomILb[01]EEv6LjArgsi):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 2
+    for name, body in kernels:
+        assert body.count("s_load_dwordx16") >= 3, name
