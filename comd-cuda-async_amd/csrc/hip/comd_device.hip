@@ -313,17 +313,20 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
    LjArgs a = makeLjArgs(sim, num_cells, cells_list);
    ForceTimer timer(S(stream));
    if (method == CTA_CELL) {
-      static bool attrSet = false;
-      if (!attrSet) {
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell, hipFuncAttributeMaxDynamicSharedMemorySize, LJ_CTA_LDS_BYTES));
-         attrSet = true;
+      const size_t lds = ljCtaLdsBytes(sim->maxAtoms);
+      static size_t attrSet = 0;
+      if (lds > attrSet) {
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         attrSet = lds;
       }
-      if (27L * sim->maxAtoms > 65535) { fprintf(stderr, "ljForceGpu: cta_cell needs 27*maxAtoms < 65536\n"); exit(-1); }
-      hipLaunchKernelGGL(LJ_Force_cta_cell, dim3(num_cells), dim3(LJ_CTA_THREADS), LJ_CTA_LDS_BYTES, S(stream), a, sim->status);
+      // threads = atoms of the fullest cell the host has seen (+16), rounded to whole waves, at most 256; each thread can own two atoms
+      int threads = sim->maxAtoms < 256 ? sim->maxAtoms : 256;
+      if (sim->max_atoms_cell > 0 && ((sim->max_atoms_cell + 16 + 63) / 64) * 64 < threads) threads = ((sim->max_atoms_cell + 16 + 63) / 64) * 64;
+      if (sim->maxAtoms > 2 * threads) { fprintf(stderr, "ljForceGpu: cta_cell supports at most 512 atoms per cell\n"); exit(-1); }
+      hipLaunchKernelGGL(LJ_Force_cta_cell, dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status);
    } else {
-      // Measured on MI355X (LJ 80^3): workgroup = cap/64 = 4 waves per cell with the tail wave exiting at once runs the kernel in
-      // 4.73 ms; sizing the workgroup to the 3 live waves (max_atoms_cell) 6.05 ms; single-wave workgroups 5.64 ms.  The waves of one
-      // cell walk the same neighbour data in step (shared scalar-cache lines), and fewer, wider workgroups keep that locality.
+      // Measured on MI355X (LJ 80^3): a workgroup of the 3 live waves per cell runs the kernel in 3.94 ms, cap/64 = 4 waves per cell (the
+      // tail wave exits at once) in 4.72 ms, single-wave workgroups in 5.64 ms.
       // waves per cell: sized to the occupancy the host last saw (+16 atoms of slack), never more than cap/64.  Cells that outgrow the
       // estimate stay correct (their waves take extra chunks).  COMD_LJ_WAVES=k forces k (tests use 1 to exercise the extra-chunk path).
       int w = sim->maxAtoms / 64;

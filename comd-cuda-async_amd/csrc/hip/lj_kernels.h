@@ -162,100 +162,110 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
 }
 
 // ---------------------------------------------------------------------------------------------------
-// workgroup per cell, 512 threads = 8 waves.  Dynamic LDS: 3 * LJ_CTA_MAXCAND doubles of candidate
-// positions + one 128-entry pair queue per wave.
-#define LJ_CTA_THREADS 512
-#define LJ_CTA_WAVES   (LJ_CTA_THREADS / 64)
-#define LJ_CTA_MAXCAND 6400
-#define LJ_CTA_QUEUE   128
-#define LJ_CTA_LDS_BYTES (3 * LJ_CTA_MAXCAND * 8 + LJ_CTA_WAVES * LJ_CTA_QUEUE * 2 + 32 * 4)
+// CTA per link cell (the reference's LJ_Force_cta_cell shape, gpu_lj_cta_cell.h:29-122): one workgroup per cell, one thread
+// per atom, neighbour positions staged in LDS and read back as wave-wide broadcasts.  The 27 stencil cells are staged in nine
+// slabs of three cells (<= 3 * cap atoms, 3 x 8 B each = 18 KB at cap 256), small enough that LDS never limits how many workgroups share
+// a CU; the reference stages 128 atoms at a time behind two barriers per tile, here a slab costs two barriers per ~440 atoms.
+// Inside a slab every lane walks the same j sequence, so each ds_read_b128 (two neighbours per read) is a broadcast.
+#define LJ_CTA_CELLS     3                 // stencil cells staged per slab: 27 / 3 = 9 slabs, 13 KB of LDS -> the CU fills up with workgroups
+static inline size_t ljCtaLdsBytes(int cap) { return (size_t)3 * (LJ_CTA_CELLS * cap + 8) * 8 + 16 * 4; }   // slab capacity = LJ_CTA_CELLS * cap atoms
 
-__global__ __launch_bounds__(LJ_CTA_THREADS)
+// all lanes read the same neighbour pair (LDS broadcast); NA = atoms per thread
+template <int NA>
+__device__ __forceinline__ void slabLoop(const double* sx, const double* sy, const double* sz, int nSlab, const LjArgs& a,
+                                         const double (&xi)[2], const double (&yi)[2], const double (&zi)[2],
+                                         double (&fx)[2], double (&fy)[2], double (&fz)[2], double (&e)[2])
+{
+   // eight neighbours per trip: the twelve 16-byte LDS reads are issued together, then evaluated (the slab is padded to a multiple of 8)
+   for (int j = 0; j < nSlab; j += 8) {
+      double2 X[4], Y[4], Z[4];
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+         X[v] = *reinterpret_cast<const double2*>(sx + j + 2 * v);
+         Y[v] = *reinterpret_cast<const double2*>(sy + j + 2 * v);
+         Z[v] = *reinterpret_cast<const double2*>(sz + j + 2 * v);
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) {
+#pragma unroll
+         for (int u = 0; u < NA; ++u) {
+            {
+               const double dx = xi[u] - X[v].x, dy = yi[u] - Y[v].x, dz = zi[u] - Z[v].x;
+               const double r2 = dx*dx + dy*dy + dz*dz;
+               if (r2 <= a.rc2 && r2 > 0.0) ljPair<true>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
+            }
+            {
+               const double dx = xi[u] - X[v].y, dy = yi[u] - Y[v].y, dz = zi[u] - Z[v].y;
+               const double r2 = dx*dx + dy*dy + dz*dz;
+               if (r2 <= a.rc2 && r2 > 0.0) ljPair<true>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
+            }
+         }
+      }
+   }
+}
+
+__global__ __launch_bounds__(256)
 void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+   const int slabCap = LJ_CTA_CELLS * a.cap + 8;            // cannot overflow: a cell never holds more than cap atoms
    double* sx = (double*)ldsRaw;
-   double* sy = sx + LJ_CTA_MAXCAND;
-   double* sz = sy + LJ_CTA_MAXCAND;
-   unsigned short* qAll = (unsigned short*)(sz + LJ_CTA_MAXCAND);
-   int* sOff = (int*)(qAll + LJ_CTA_WAVES * LJ_CTA_QUEUE);          // [28] candidate offsets per stencil cell
-
-   const int lane = threadIdx.x & 63;
-   const int wave = uniform(threadIdx.x >> 6);
-   unsigned short* q = qAll + wave * LJ_CTA_QUEUE;
+   double* sy = sx + slabCap;
+   double* sz = sy + slabCap;
+   int* sOff = (int*)(sz + slabCap);                        // offsets of the slab's cells
 
    const int ci = xcdRemap(blockIdx.x, gridDim.x);
    const int iBox = a.cells ? a.cells[ci] : ci;
    const int ni = a.nAtoms[iBox];
    const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
+   const int nThreads = blockDim.x;
 
-   // stage: offsets (one wave), then positions of every stencil cell, compacted, own cell first
-   if (threadIdx.x < 64) {
-      int cnt = lane < 27 ? a.nAtoms[nb[lane]] : 0;
-      int incl = cnt;
+   // each thread owns up to two atoms (cells of up to 2 * blockDim atoms): t and t + blockDim
+   double xi[2], yi[2], zi[2], fx[2] = {0.0, 0.0}, fy[2] = {0.0, 0.0}, fz[2] = {0.0, 0.0}, e[2] = {0.0, 0.0};
+   bool own[2];
 #pragma unroll
-      for (int d = 1; d < 32; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-      if (lane < 27) sOff[lane] = incl - cnt;
-      if (lane == 26) sOff[27] = incl;
+   for (int u = 0; u < 2; ++u) {
+      const int i = threadIdx.x + u * nThreads;
+      own[u] = i < ni;
+      const size_t io = (size_t)iBox * a.cap + (own[u] ? i : 0);
+      xi[u] = a.rx[io]; yi[u] = a.ry[io]; zi[u] = a.rz[io];
    }
-   __syncthreads();
-   const int nCand = sOff[27];
-   if (nCand > LJ_CTA_MAXCAND) {            // cannot happen for cap*27 <= MAXCAND; flag instead of corrupting LDS
-      if (threadIdx.x == 0) atomicOr(&status[0], 2);
-      return;
-   }
-   for (int k = 0; k < 27; ++k) {
-      const int jBox = nb[k];
-      const int off = sOff[k], nj = sOff[k + 1] - off;
-      for (int j = threadIdx.x; j < nj; j += LJ_CTA_THREADS) {
-         size_t o = (size_t)jBox * a.cap + j;
-         sx[off + j] = a.rx[o]; sy[off + j] = a.ry[o]; sz[off + j] = a.rz[o];
-      }
-   }
-   __syncthreads();
+   const bool second = ni > nThreads;                        // workgroup-uniform
 
-   for (int i = wave; i < ni; i += LJ_CTA_WAVES) {          // wave-uniform i; own cell occupies candidates [0, ni)
-      const double xi = sx[i], yi = sy[i], zi = sz[i];
-      double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
-      int qn = 0;                                           // wave-uniform queue fill
-      for (int j0 = 0; j0 < nCand; j0 += 64) {
-         const int j = j0 + lane;
-         bool hit = false;
-         if (j < nCand) {
-            double dx = xi - sx[j], dy = yi - sy[j], dz = zi - sz[j];
-            double r2 = dx*dx + dy*dy + dz*dz;
-            hit = (r2 <= a.rc2) && (r2 > 0.0);              // same guard as the reference (no self pair, no divide by zero)
-         }
-         const unsigned long long m = __ballot(hit);
-         if (hit) {
-            int pos = qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            q[pos] = (unsigned short)j;
-         }
-         qn += __popcll(m);
-         __builtin_amdgcn_wave_barrier();
-         if (qn >= 64) {                                    // evaluate one full batch at 64/64 lanes
-            const int jj = q[lane];
-            double dx = xi - sx[jj], dy = yi - sy[jj], dz = zi - sz[jj];
-            ljPair<true>(dx, dy, dz, dx*dx + dy*dy + dz*dz, a, fx, fy, fz, e);
-            qn -= 64;
-            const unsigned short carry = q[64 + lane];      // move the overflow to the front
-            __builtin_amdgcn_wave_barrier();
-            if (lane < qn) q[lane] = carry;
-            __builtin_amdgcn_wave_barrier();
+   for (int slab = 0; slab < 27 / LJ_CTA_CELLS; ++slab) {
+      __syncthreads();                                       // previous slab fully consumed
+      if (threadIdx.x < 64) {
+         const int lane = threadIdx.x;
+         const int cnt = lane < LJ_CTA_CELLS ? a.nAtoms[nb[slab * LJ_CTA_CELLS + lane]] : 0;
+         int incl = cnt;
+#pragma unroll
+         for (int d = 1; d < 16; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+         if (lane <= LJ_CTA_CELLS) sOff[lane] = incl - cnt;    // lane LJ_CTA_CELLS: cnt = 0 -> total
+      }
+      __syncthreads();
+      const int nSlab = sOff[LJ_CTA_CELLS];
+      for (int q = 0; q < LJ_CTA_CELLS; ++q) {
+         const int jBox = nb[slab * LJ_CTA_CELLS + q];
+         const int off = sOff[q], nj = sOff[q + 1] - off;
+         for (int j = threadIdx.x; j < nj; j += nThreads) {
+            const size_t o = (size_t)jBox * a.cap + j;
+            sx[off + j] = a.rx[o]; sy[off + j] = a.ry[o]; sz[off + j] = a.rz[o];
          }
       }
-      if (lane < qn) {                                      // tail batch
-         const int jj = q[lane];
-         double dx = xi - sx[jj], dy = yi - sy[jj], dz = zi - sz[jj];
-         ljPair<true>(dx, dy, dz, dx*dx + dy*dy + dz*dz, a, fx, fy, fz, e);
+      if (threadIdx.x < 8 && nSlab + threadIdx.x < ((nSlab + 7) & ~7)) {          // pad to a multiple of 8 with far-away points
+         sx[nSlab + threadIdx.x] = 1.0e30; sy[nSlab + threadIdx.x] = 1.0e30; sz[nSlab + threadIdx.x] = 1.0e30;
       }
-      __builtin_amdgcn_wave_barrier();
-      fx = waveSum(fx); fy = waveSum(fy); fz = waveSum(fz); e = waveSum(e);
-      if (lane == 0) {
-         const size_t io = (size_t)iBox * a.cap + i;
-         const double fs = 24.0 * a.eps;
-         a.fx[io] = fx * fs; a.fy[io] = fy * fs; a.fz[io] = fz * fs;
-         a.e[io] = e * 2.0 * a.eps;
-      }
+      __syncthreads();
+
+      if (!second) slabLoop<1>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e);       // the common case: one atom per thread
+      else         slabLoop<2>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e);
    }
+   const double fs = 24.0 * a.eps;
+#pragma unroll
+   for (int u = 0; u < 2; ++u)
+      if (own[u]) {
+         const size_t io = (size_t)iBox * a.cap + threadIdx.x + u * nThreads;
+         a.fx[io] = fx[u] * fs; a.fy[io] = fy[u] * fs; a.fz[io] = fz[u] * fs;
+         a.e[io] = e[u] * 2.0 * a.eps;
+      }
 }

@@ -64,8 +64,6 @@ def test_lj_cells_larger_than_the_launch_estimate(gpu, orc, monkeypatch):
 def test_reference_recorded_forces(gpu, case, method):
     """The -r 0.1 known answers recorded from the unmodified reference."""
     ref = S[case]
-    if case == "lj_8_delta" and method == "cta_cell":
-        pytest.skip("8^3 LJ has 256-atom cells: 27 of them exceed the cta_cell kernel's LDS staging (6400 atoms)")
     with gpu.Simulation(_args(ref["nx"], ref["eam"], ref["delta"], method)) as sim:
         _, u, _ = _per_atom(sim)
         assert abs(u - ref["U_per_atom"]) < 1e-12
