@@ -207,3 +207,33 @@ def test_full_size_properties(gpu, eam, method, steps):
         g = np.where(mask, c["gid"][:nl], np.iinfo(np.int32).max)
         assert np.all(np.diff(g.astype(np.int64), axis=1) >= 0)
         assert np.array_equal(np.sort(c["gid"][:nl][mask]), np.arange(4 * 80 ** 3))
+
+
+# ---------------------------------------------------------------- the executable: CLI, stdout table, validation block, YAML
+def test_comd_hip_executable_report(gpu, tmp_path):
+    """`comd-hip` is the reference's CoMD binary for this path: same flags, same table (CoMD.c:478-493), same validation block
+    (CoMD.c:421-438), a YAML side file (yamlOutput.c:45-67).  LJ 20^3, 20 steps: the rows must carry the reference's energies."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "comd-cuda-async_amd", "csrc", "comd-hip")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run([exe, "-x", "20", "-y", "20", "-z", "20", "-N", "20", "-n", "10", "-d", os.path.join(root, "pots")],
+                          capture_output=True, text=True, cwd=tmp_path, env=env, timeout=300)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    out = proc.stdout
+    assert "#  Loop   Time(fs)       Total Energy   Potential Energy     Kinetic Energy  Temperature   (us/atom)     # Atoms" in out
+    rows = {int(m.group(1)): [float(v) for v in m.group(2).split()]
+            for m in re.finditer(r"^\s+(\d+)\s+(\d+\.\d+\s+-\d+\.\d+\s+-\d+\.\d+\s+\d+\.\d+\s+\d+\.\d+\s+\d+\.\d+\s+\d+)\s*$", out, flags=re.M)}
+    assert set(rows) == {0, 10, 20}
+    ref = S["lj_20"]
+    assert abs(rows[0][1] - ref["step0"]["E"]) < 2e-12 and abs(rows[0][2] - ref["step0"]["U"]) < 2e-12
+    assert abs(rows[10][1] - ref["E_at"]["10"]) < 2e-12
+    assert rows[0][4] == 600.0 and rows[20][6] == 32000
+    assert "Simulation Validation:" in out and "no atoms lost" in out and "eFinal/eInitial : 1.0000" in out
+    assert "Average all atom update rate:" in out and "Timings for Rank 0" in out
+    yamls = [f for f in os.listdir(tmp_path) if f.endswith(".yaml")]
+    assert len(yamls) == 1
+    y = open(os.path.join(tmp_path, yamls[0])).read()
+    for key in ("Mini-Application Name", "Command Line Parameters:", "nx: 20", "Simulation data:", "Potential data:", "Performance Results:", "AtomUpdateRate:"):
+        assert key in y, key
