@@ -150,7 +150,8 @@ enum HaloAxisOrder { HALO_X_AXIS, HALO_Y_AXIS, HALO_Z_AXIS };
 typedef struct HaloExchangeSt {
    int nbrRank[6];
    int bufCapacity;                       /* bytes per message buffer */
-   int (*loadBuffer)(void* parms, void* data, int face, char* buf);
+   int (*loadBuffer)(void* parms, void* data, int face, char* buf);       /* returns bytes, or -1: "ask msgBytes when you need it" */
+   int (*msgBytes)(void* parms, void* data, int face, char* buf);         /* optional: size of a packed device message (blocks) */
    void (*unloadBuffer)(void* parms, void* data, int face, int bufSize, char* buf);
    void (*destroy)(void* parms);
    void* parms;

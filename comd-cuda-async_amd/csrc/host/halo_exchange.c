@@ -89,7 +89,15 @@ static int loadAtomsBuffer(void* vparms, void* data, int face, char* buf)
    SimFlat* sim = (SimFlat*)data;
    compactCellsGpu(buf, parms->nCells[face], parms->cellListGpu[face], &sim->gpu, parms->d_cellOffsets,
                    parms->shift[face], parms->capacityAtoms, sim->gpu.boundary_stream);
-   if (getNRanks() == 1) return -1;           /* own periodic image: the count stays on the device */
+   return -1;            /* the count stays on the device (message header); exchangeData asks msgBytes only if a peer needs it */
+}
+
+/* blocking: the reference reads this count back after every pack (gpu_kernels.cu:534-535); here only when the message leaves the rank,
+ * and after BOTH faces of the axis have been packed, so one stream drain serves the two reads */
+static int atomsMsgBytes(void* vparms, void* data, int face, char* buf)
+{
+   (void)vparms; (void)face;
+   SimFlat* sim = (SimFlat*)data;
    int n = atomMsgCountGpu(&sim->gpu, buf, sim->gpu.boundary_stream);
    return COMD_ATOM_MSG_HEADER + n * COMD_ATOM_MSG_BYTES_PER_ATOM;
 }
@@ -120,6 +128,7 @@ HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDev
    parms->capacityAtoms = maxSize * 2 * boxes->maxAtoms;
    hh->bufCapacity = COMD_ATOM_MSG_HEADER + parms->capacityAtoms * COMD_ATOM_MSG_BYTES_PER_ATOM;
    hh->loadBuffer = loadAtomsBuffer;
+   hh->msgBytes = atomsMsgBytes;
    hh->unloadBuffer = unloadAtomsBuffer;
    hh->destroy = destroyAtomsExchange;
    parms->nCells[HALO_X_MINUS] = parms->nCells[HALO_X_PLUS] = 2 * size0;
@@ -148,7 +157,14 @@ static int loadForceBuffer(void* vparms, void* vdata, int face, char* buf)
    ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
    SimFlat* s = (SimFlat*)vdata;
    loadForceBufferFromGpu((real_t*)buf, parms->nCells[face], parms->sendCellsGpu[face], parms->sendOffsetsGpu[face], &s->gpu, s->gpu.boundary_stream);
-   if (getNRanks() == 1) return -1;
+   return -1;
+}
+
+static int forceMsgBytes(void* vparms, void* vdata, int face, char* buf)
+{
+   (void)buf;
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
    int n = comdReadDeviceInt(parms->sendOffsetsGpu[face] + parms->nCells[face], s->gpu.boundary_stream);
    return n * (int)sizeof(real_t);
 }
@@ -182,6 +198,7 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
    parms->capacityAtoms = maxSize * boxes->maxAtoms;
    hh->bufCapacity = parms->capacityAtoms * (int)sizeof(real_t);
    hh->loadBuffer = loadForceBuffer;
+   hh->msgBytes = forceMsgBytes;
    hh->unloadBuffer = unloadForceBuffer;
    hh->destroy = destroyForceExchange;
    parms->nCells[HALO_X_MINUS] = parms->nCells[HALO_X_PLUS] = size0;
@@ -248,6 +265,8 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
       hh->unloadBuffer(hh->parms, data, faceP, nSendM, hh->sendBufM);
       return;
    }
+   if (nSendM < 0 && hh->msgBytes) nSendM = hh->msgBytes(hh->parms, data, faceM, hh->sendBufM);
+   if (nSendP < 0 && hh->msgBytes) nSendP = hh->msgBytes(hh->parms, data, faceP, hh->sendBufP);
    int nRecvP, nRecvM;
    if (hh->deviceBuffers) {
       SimFlat* sim = (SimFlat*)data;
