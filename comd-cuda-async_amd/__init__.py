@@ -27,6 +27,9 @@ class HostAtoms(ctypes.Structure):
 
 SENDRECV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
                                ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
+SENDRECV2_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p,
+                                ctypes.POINTER(ctypes.c_int))
 ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 BCAST_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 BARRIER_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
@@ -38,7 +41,7 @@ UNLOAD_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_in
 
 class CommTransport(ctypes.Structure):
     """include/comd_hip.h CommTransport"""
-    _fields_ = [("ctx", ctypes.c_void_p), ("sendrecv", SENDRECV_FN), ("allreduce", ALLREDUCE_FN),
+    _fields_ = [("ctx", ctypes.c_void_p), ("sendrecv", SENDRECV_FN), ("sendrecv2", SENDRECV2_FN), ("allreduce", ALLREDUCE_FN),
                 ("bcast", BCAST_FN), ("barrier", BARRIER_FN)]
 
 
@@ -285,7 +288,8 @@ class GlooTransport:
         self.dist, self.torch, self.np = dist, torch, np
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.hip = None
-        self._keep = (SENDRECV_FN(self._sendrecv), ALLREDUCE_FN(self._allreduce), BCAST_FN(self._bcast), BARRIER_FN(self._barrier))
+        self._keep = (SENDRECV_FN(self._sendrecv), SENDRECV2_FN(self._sendrecv2), ALLREDUCE_FN(self._allreduce), BCAST_FN(self._bcast),
+                      BARRIER_FN(self._barrier))
         self.struct = CommTransport(None, *self._keep)
 
     def _exchange(self, send_bytes, dest, source, recv_cap):
@@ -326,6 +330,11 @@ class GlooTransport:
             data = self._exchange(ctypes.string_at(send_buf, send_len), dest, source, recv_cap)
             ctypes.memmove(recv_buf, data, len(data))
         return len(data)
+
+    def _sendrecv2(self, ctx, send_m, n_m, dst_m, recv_p, send_p, n_p, dst_p, recv_m, recv_cap, device, stream, n_recv):
+        # same pairing as the RCCL transport: my minus-face message lands in dst_m's "from plus" buffer and vice versa
+        n_recv[0] = self._sendrecv(ctx, send_m, n_m, dst_m, recv_p, recv_cap, dst_p, device, stream)
+        n_recv[1] = self._sendrecv(ctx, send_p, n_p, dst_p, recv_m, recv_cap, dst_m, device, stream)
 
     def _allreduce(self, ctx, buf, count, dtype):
         np, torch, dist = self.np, self.torch, self.dist

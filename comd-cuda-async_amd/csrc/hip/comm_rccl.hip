@@ -21,8 +21,8 @@
 static ncclComm_t g_comm = nullptr;
 static int g_rank = 0, g_nRanks = 1;
 static hipStream_t g_stream = nullptr;      // reductions / broadcasts
-static int* g_dSizes = nullptr;             // device [2]: send size, recv size
-static int* g_hSizes = nullptr;             // pinned [2]
+static int* g_dSizes = nullptr;             // device [4]: two send sizes, two receive sizes
+static int* g_hSizes = nullptr;             // pinned [4]
 static void* g_dScratch = nullptr;          // device scratch for small host-buffer collectives
 static const size_t kScratchBytes = 1 << 20;
 static std::string g_idFile;
@@ -46,6 +46,33 @@ static int rcclSendrecv(void*, const void* sendBuf, int sendLen, int dest, void*
    if (recvLen > 0) NCCLC(ncclRecv(recvBuf, (size_t)recvLen, ncclChar, source, g_comm, st));
    NCCLC(ncclGroupEnd());
    return recvLen;
+}
+
+// both faces of an axis phase: one size handshake (two ints each way), one payload group of up to four transfers
+static void rcclSendrecv2(void*, const void* sendM, int nSendM, int dstM, void* recvP, const void* sendP, int nSendP, int dstP, void* recvM,
+                          int recvCap, int device, comdStream_t stream, int nRecv[2])
+{
+   hipStream_t st = (hipStream_t)stream;
+   if (!device) { fprintf(stderr, "Rank %d: RCCL transport moves device buffers only\n", g_rank); exit(-1); }
+   g_hSizes[0] = nSendM; g_hSizes[1] = nSendP;
+   HIPC(hipMemcpyAsync(g_dSizes, g_hSizes, 2 * sizeof(int), hipMemcpyHostToDevice, st));
+   NCCLC(ncclGroupStart());
+   NCCLC(ncclSend(g_dSizes, 1, ncclInt, dstM, g_comm, st));          // my minus-face size -> minus neighbour
+   NCCLC(ncclSend(g_dSizes + 1, 1, ncclInt, dstP, g_comm, st));      // my plus-face size  -> plus neighbour
+   NCCLC(ncclRecv(g_dSizes + 2, 1, ncclInt, dstP, g_comm, st));      // plus neighbour's minus-face size  (arrives in recvP)
+   NCCLC(ncclRecv(g_dSizes + 3, 1, ncclInt, dstM, g_comm, st));      // minus neighbour's plus-face size  (arrives in recvM)
+   NCCLC(ncclGroupEnd());
+   HIPC(hipMemcpyAsync(g_hSizes + 2, g_dSizes + 2, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+   HIPC(hipStreamSynchronize(st));
+   const int nP = g_hSizes[2], nM = g_hSizes[3];
+   if (nP > recvCap || nM > recvCap) { fprintf(stderr, "Rank %d: incoming halo message (%d / %d B) exceeds the buffer (%d B)\n", g_rank, nP, nM, recvCap); exit(-1); }
+   NCCLC(ncclGroupStart());
+   if (nSendM > 0) NCCLC(ncclSend(sendM, (size_t)nSendM, ncclChar, dstM, g_comm, st));
+   if (nSendP > 0) NCCLC(ncclSend(sendP, (size_t)nSendP, ncclChar, dstP, g_comm, st));
+   if (nP > 0) NCCLC(ncclRecv(recvP, (size_t)nP, ncclChar, dstP, g_comm, st));
+   if (nM > 0) NCCLC(ncclRecv(recvM, (size_t)nM, ncclChar, dstM, g_comm, st));
+   NCCLC(ncclGroupEnd());
+   nRecv[0] = nP; nRecv[1] = nM;
 }
 
 static void rcclAllreduce(void*, void* buf, int count, int dtype)
@@ -90,11 +117,12 @@ extern "C" int comdCommInitRank(const char* id128, int rank, int nRanks, CommTra
    memcpy(&id, id128, sizeof id);
    NCCLC(ncclCommInitRank(&g_comm, nRanks, id, rank));
    HIPC(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-   HIPC(hipMalloc((void**)&g_dSizes, 2 * sizeof(int)));
-   HIPC(hipHostMalloc((void**)&g_hSizes, 2 * sizeof(int), hipHostMallocDefault));
+   HIPC(hipMalloc((void**)&g_dSizes, 4 * sizeof(int)));
+   HIPC(hipHostMalloc((void**)&g_hSizes, 4 * sizeof(int), hipHostMallocDefault));
    HIPC(hipMalloc(&g_dScratch, kScratchBytes));
    out->ctx = nullptr;
    out->sendrecv = rcclSendrecv;
+   out->sendrecv2 = rcclSendrecv2;
    out->allreduce = rcclAllreduce;
    out->bcast = rcclBcast;
    out->barrier = rcclBarrier;

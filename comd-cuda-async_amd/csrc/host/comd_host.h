@@ -51,6 +51,8 @@ void barrierParallel(void);
 void timestampBarrier(const char* msg);
 int  sendReceiveParallel(void* sendBuf, int sendLen, int dest, void* recvBuf, int recvLen, int source);
 int  sendReceiveDevice(void* sendBuf, int sendLen, int dest, void* recvBuf, int recvLen, int source, comdStream_t stream);
+void sendReceiveDevice2(void* sendM, int nSendM, int dstM, void* recvP, void* sendP, int nSendP, int dstP, void* recvM,
+                        int recvCap, comdStream_t stream, int nRecv[2]);
 void addIntParallel(int* sendBuf, int* recvBuf, int count);
 void addRealParallel(real_t* sendBuf, real_t* recvBuf, int count);
 void addDoubleParallel(double* sendBuf, double* recvBuf, int count);

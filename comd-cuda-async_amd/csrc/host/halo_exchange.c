@@ -270,8 +270,10 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
    int nRecvP, nRecvM;
    if (hh->deviceBuffers) {
       SimFlat* sim = (SimFlat*)data;
-      nRecvP = sendReceiveDevice(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->bufCapacity, nbrP, sim->gpu.boundary_stream);
-      nRecvM = sendReceiveDevice(hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity, nbrM, sim->gpu.boundary_stream);
+      int nRecv[2];
+      sendReceiveDevice2(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity,
+                         sim->gpu.boundary_stream, nRecv);
+      nRecvP = nRecv[0]; nRecvM = nRecv[1];
    } else {
       nRecvP = sendReceiveParallel(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->bufCapacity, nbrP);
       nRecvM = sendReceiveParallel(hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity, nbrM);

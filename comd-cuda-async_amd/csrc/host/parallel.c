@@ -56,6 +56,18 @@ int sendReceiveDevice(void* sendBuf, int sendLen, int dest, void* recvBuf, int r
    return transport.sendrecv(transport.ctx, sendBuf, sendLen, dest, recvBuf, recvLen, source, 1, stream);
 }
 
+/* both messages of one axis phase (device buffers).  Uses the transport's fused call when it has one. */
+void sendReceiveDevice2(void* sendM, int nSendM, int dstM, void* recvP, void* sendP, int nSendP, int dstP, void* recvM,
+                        int recvCap, comdStream_t stream, int nRecv[2])
+{
+   if (haveTransport && transport.sendrecv2) {
+      transport.sendrecv2(transport.ctx, sendM, nSendM, dstM, recvP, sendP, nSendP, dstP, recvM, recvCap, 1, stream, nRecv);
+      return;
+   }
+   nRecv[0] = sendReceiveDevice(sendM, nSendM, dstM, recvP, recvCap, dstP, stream);
+   nRecv[1] = sendReceiveDevice(sendP, nSendP, dstP, recvM, recvCap, dstM, stream);
+}
+
 void addIntParallel(int* sendBuf, int* recvBuf, int count)
 {
    memmove(recvBuf, sendBuf, (size_t)count * sizeof(int));

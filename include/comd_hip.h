@@ -249,6 +249,11 @@ typedef struct CommTransportSt {
     * and the transfer is ordered on `stream`.  Returns the number of bytes received (<= recvCap). */
    int  (*sendrecv)(void* ctx, const void* sendBuf, int sendLen, int dest, void* recvBuf, int recvCap, int source,
                     int device, comdStream_t stream);
+   /* optional (may be NULL): both messages of one axis phase in a single call -- send bufM to dstM and bufP to dstP, receive what
+    * dstP sends through its minus face into recvP and what dstM sends through its plus face into recvM.  One size handshake and one
+    * payload group instead of two of each.  Writes the received byte counts to nRecv[0] (recvP) and nRecv[1] (recvM). */
+   void (*sendrecv2)(void* ctx, const void* sendM, int nSendM, int dstM, void* recvP, const void* sendP, int nSendP, int dstP, void* recvM,
+                     int recvCap, int device, comdStream_t stream, int nRecv[2]);
    void (*allreduce)(void* ctx, void* buf, int count, int dtype /* 0 int sum, 1 double sum, 2 int max */);
    void (*bcast)(void* ctx, void* buf, int len, int root);
    void (*barrier)(void* ctx);
