@@ -86,15 +86,6 @@ __device__ __forceinline__ double pairSum(double pa, double pb)
    return v;
 }
 
-// whole wave: lane 63 holds the total
-__device__ __forceinline__ double waveSumToLane63(double v)
-{
-   v = rowSum(v);
-   v += dppMove64<0x142, 0xA>(v);      // row_bcast:15 -> rows 1, 3
-   v += dppMove64<0x143, 0xC>(v);      // row_bcast:31 -> rows 2, 3
-   return v;
-}
-
 __device__ __forceinline__ int waveSumInt(int v)
 {
 #pragma unroll

@@ -9,11 +9,10 @@
 // Tables are the reference's default quadratic interpolation (gpu_common.h:48-86); the -P spline mode is out of scope.
 //
 //  thread_atom : one thread per cell slot (cell*cap + i), tables read through L1/L2.
-//  cta_cell    : 4 waves per workgroup, each wave owns one cell at a time.  phi/rho tables live in LDS for the whole
-//                (persistent) workgroup; the wave stages the positions (and F' in pass 3) of its 27 stencil cells,
-//                compacted, in LDS, spreads the candidates over its lanes, compacts accepted pairs through
-//                ballot/mbcnt into an LDS queue and evaluates them at full lane occupancy; per-atom sums leave
-//                through a ds_bpermute butterfly.
+//  cta_cell    : persistent workgroups of 4 waves, each wave owns one cell at a time.  phi/rho tables live in LDS for the
+//                workgroup's lifetime; the wave stages the positions of its 27 stencil cells, compacted, in LDS, spreads
+//                the candidates over its lanes, compacts accepted pairs through v_cmp/mbcnt into an LDS queue and evaluates
+//                them at full lane occupancy; the sums of two atoms at a time leave through v_permlane32_swap + DPP.
 #pragma once
 #include "device_common.h"
 
@@ -142,17 +141,6 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
       a.fx[iOff] = fx; a.fy[iOff] = fy; a.fz[iOff] = fz;
       if (STEP == 1) { a.e[iOff] = 0.5 * e; a.rhobar[iOff] = rb; }
    }
-}
-
-// merge the per-lane partial sums of two atoms across the lane bit `BIT`: lanes with the bit clear end up holding
-// atom A's sums, lanes with it set atom B's, each already added over the lane pair (l, l ^ BIT)
-template <int BIT>
-__device__ __forceinline__ double mergePair(double pa, double pb, int lane)
-{
-   const bool hi = (lane & BIT) != 0;
-   const double keep = hi ? pb : pa;
-   const double send = hi ? pa : pb;
-   return keep + bpermute64(send, lane ^ BIT);
 }
 
 template <int STEP>

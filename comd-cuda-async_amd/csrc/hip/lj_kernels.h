@@ -8,11 +8,9 @@
 //  thread_atom : one wave = 64 consecutive slots of ONE link cell, so the neighbour atom j is the same for
 //                all lanes -> j positions come through the scalar unit (s_load into SGPRs), the vector unit
 //                only does the distance test and the pair evaluation.  No LDS, no atom lists.
-//  cta_cell    : one workgroup per link cell; the positions of all 27 stencil cells are staged, compacted,
-//                in LDS once; each wave owns one i atom at a time and spreads the candidates over its 64
-//                lanes; accepted pairs are compacted (ballot + mbcnt) into a per-wave LDS queue and evaluated
-//                64 at a time at full lane occupancy; per-atom force/energy leave the wave through a
-//                ds_bpermute butterfly.
+//                The under-filled tail wave of a cell replicates its atoms across the lanes, one stencil subset per replica.
+//  cta_cell    : one workgroup per link cell, one thread per atom (the reference's shape); the stencil cells are staged
+//                in LDS three at a time and read back as wave-wide broadcasts, eight neighbours per trip.
 #pragma once
 #include "device_common.h"
 
