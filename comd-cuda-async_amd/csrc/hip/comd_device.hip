@@ -266,12 +266,13 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
    int st[4];
    HIP_CHECK(hipDeviceSynchronize());
    HIP_CHECK(hipMemcpy(st, sim->status, sizeof st, hipMemcpyDeviceToHost));
-   if (st[0] | st[1] | st[2]) {
+   if (st[0] | st[1] | st[2] | st[3]) {
       fprintf(stderr, "Rank %d, GPU: %d, %s: ", g_rank, sim->deviceId, where);
       if (st[0] & 1) fprintf(stderr, "a link cell overflowed its %d slots (raise --maxAtoms); ", sim->maxAtoms);
       if (st[0] & 2) fprintf(stderr, "a cell stencil holds more atoms than the cta_cell kernel can stage; ");
       if (st[1])     fprintf(stderr, "an atom moved beyond the halo region and was lost; ");
       if (st[2])     fprintf(stderr, "a halo message overflowed its buffer; ");
+      if (st[3])     fprintf(stderr, "an atom has more neighbours inside the cutoff than the EAM cta_cell pair queue holds (use -m thread_atom); ");
       fprintf(stderr, "\n");
       exit(-1);
    }
@@ -367,15 +368,23 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
    ForceTimer timer(st);
    if (method == CTA_CELL) {
-      const size_t lds = eamCtaLdsBytes(STEP, a.rho.n, a.phi.n);
-      static bool attrSet = false;
-      if (!attrSet) {
-         HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         attrSet = true;
-      }
+      // funcfl tables (500 samples) live in the LDS; setfl tables (10000 samples, 80 KB each) stay in L2 and the LDS
+      // goes to a wider candidate list instead (longer cutoff -> more atoms per stencil)
+      const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
+      const int tablesInLds = tableBytes <= 32 * 1024;
       int grid = ceilDiv(num_cells, EAM_CTA_WAVES);
       if (grid > 2048) grid = 2048;             // persistent: 8 workgroups per CU's worth, each wave strides over cells
-      hipLaunchKernelGGL(EAM_Force_cta_cell<STEP>, dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+      if (tablesInLds) {
+         const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, tableBytes);
+         static bool attrSet = false;
+         if (!attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = true; }
+         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+      } else {
+         const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
+         static bool attrSet = false;
+         if (!attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = true; }
+         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+      }
    } else {
       hipLaunchKernelGGL(EAM_Force_thread_atom<STEP>, dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);
    }

@@ -99,11 +99,12 @@ void EAM_Force_embed(EamArgs a)
 // partial sums of TWO atoms at a time: v_permlane32_swap puts one atom in each half of the wave, DPP row ops finish (no LDS).
 #define EAM_CTA_THREADS 256
 #define EAM_CTA_WAVES   4
-#define EAM_CTA_MAXCAND 384                        // stencil atoms a wave can stage (FCC Cu at 80^3: 256..365, mean 283); 3 workgroups per CU
+#define EAM_CTA_MAXCAND 384                        // stencil atoms a wave can stage (FCC Cu, Cu_u6 cutoff, 80^3: 256..365, mean 283); 3 workgroups per CU
+#define EAM_CTA_MAXCAND_WIDE 640                   // longer cutoffs (Mishin Cu01: 5.51 A, mean 393 per stencil); tables then stay in L2
 #define EAM_CTA_QUEUE   128
 
 // A cell whose 27-cell stencil holds more than EAM_CTA_MAXCAND atoms (small boxes have larger cells) is handled by the
-// same wave in the thread-per-atom form: lane = i atom, neighbours streamed from global memory, tables still in LDS.
+// same wave in the thread-per-atom form: lane = i atom, neighbours streamed from global memory, same tables.
 template <int STEP>
 __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int lane, const TableView& rhoT, const TableView& phiT, bool sameGrid)
 {
@@ -143,37 +144,39 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
    }
 }
 
-template <int STEP>
+template <int STEP, int MAXCAND, bool LDS_TABLES>
 __global__ __launch_bounds__(EAM_CTA_THREADS)
 void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int NV = (STEP == 1) ? 5 : 3;                   // values reduced per atom: f (3) [+ e, rhobar]
    constexpr int NC = 3;                                     // doubles staged per candidate: r; pass 3 also keeps its global slot (int)
+   // tables too large for the LDS (setfl files: 10000 samples each) are read through L2 instead
    const int nRhoPad = a.rho.n + 3, nPhiPad = (STEP == 1) ? a.phi.n + 3 : 0;
    double* sRho = (double*)ldsRaw;
-   double* sPhi = sRho + nRhoPad;
-   double* waveBase = sPhi + nPhiPad;
-   constexpr int perWaveDoubles = NC * EAM_CTA_MAXCAND + (STEP == 3 ? EAM_CTA_MAXCAND / 2 : 0) + (2 * EAM_CTA_QUEUE * 2 + 64 * 4) / 8;
+   double* sPhi = sRho + (LDS_TABLES ? nRhoPad : 0);
+   double* waveBase = sPhi + (LDS_TABLES ? nPhiPad : 0);
+   constexpr int perWaveDoubles = NC * MAXCAND + (STEP == 3 ? MAXCAND / 2 : 0) + (2 * EAM_CTA_QUEUE * 2 + 64 * 4) / 8;
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
    double* sx = waveBase + (size_t)wave * perWaveDoubles;
-   double* sy = sx + EAM_CTA_MAXCAND;
-   double* sz = sy + EAM_CTA_MAXCAND;
-   int* sSlot = (int*)(sz + EAM_CTA_MAXCAND);               // pass 3 only: global slot of each candidate, to fetch F'_j for accepted pairs
-   unsigned short* qBase = (unsigned short*)(sx + NC * EAM_CTA_MAXCAND + (STEP == 3 ? EAM_CTA_MAXCAND / 2 : 0));   // one pair queue per atom of a group
+   double* sy = sx + MAXCAND;
+   double* sz = sy + MAXCAND;
+   int* sSlot = (int*)(sz + MAXCAND);               // pass 3 only: global slot of each candidate, to fetch F'_j for accepted pairs
+   unsigned short* qBase = (unsigned short*)(sx + NC * MAXCAND + (STEP == 3 ? MAXCAND / 2 : 0));   // one pair queue per atom of a group
    int* sOff = (int*)(qBase + 2 * EAM_CTA_QUEUE);           // [32] exclusive candidate offsets of the stencil cells
    int* sBox = sOff + 32;                                    // [32] their cell ids
 
    // pass 1 on a shared r grid (funcfl): one interleaved {phi, rho} table; otherwise two separate tables
-   const bool sameGrid = (STEP == 1) && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
-   if (sameGrid) {
+   const bool sameGrid = (STEP == 1) && LDS_TABLES && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+   if (!LDS_TABLES) {
+   } else if (sameGrid) {
       for (int t = threadIdx.x; t < nRhoPad; t += EAM_CTA_THREADS) { sRho[2 * t] = a.phi.values[t]; sRho[2 * t + 1] = a.rho.values[t]; }
    } else {
       for (int t = threadIdx.x; t < nRhoPad; t += EAM_CTA_THREADS) sRho[t] = a.rho.values[t];
       if (STEP == 1) for (int t = threadIdx.x; t < nPhiPad; t += EAM_CTA_THREADS) sPhi[t] = a.phi.values[t];
    }
    __syncthreads();
-   const TableView rhoT = makeTable(a.rho, sRho), phiT = makeTable(a.phi, sPhi);
+   const TableView rhoT = makeTable(a.rho, LDS_TABLES ? sRho : a.rho.values), phiT = makeTable(a.phi, LDS_TABLES ? sPhi : a.phi.values);
 
    // cap is a power of two <= 64 for EAM (chooseMaxAtoms): `cellsPerRound` stencil cells are staged per round of 64 lanes
    const int capShift = 31 - __builtin_clz(a.cap);
@@ -185,6 +188,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
    // so the stencil planes they share stay in that XCD's 4 MiB L2 (before: 14-18x re-fetch of the positions, rocprof FETCH_SIZE).
    const int xcd = blockIdx.x & 7, lb = blockIdx.x >> 3, nlb = (gridDim.x + 7 - xcd) >> 3;
    const int cellLo = (int)((long)a.nCells * xcd / 8), cellHi = (int)((long)a.nCells * (xcd + 1) / 8);
+   int overrun = 0;
    for (int ci = cellLo + lb * EAM_CTA_WAVES + wave; ci < cellHi; ci += nlb * EAM_CTA_WAVES) {
       const int iBox = uniform(a.cells ? a.cells[ci] : ci);
       const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
@@ -200,7 +204,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
       __builtin_amdgcn_wave_barrier();
       const int nCand = uniform(sOff[27]);
       const int ni = uniform(sOff[1]);
-      if (nCand > EAM_CTA_MAXCAND) { eamCellDirect<STEP>(a, iBox, lane, rhoT, phiT, sameGrid); continue; }
+      if (nCand > MAXCAND) { eamCellDirect<STEP>(a, iBox, lane, rhoT, phiT, sameGrid); continue; }
 
       // (2) stage positions [and F'] of the stencil cells, in groups of GROUP rounds with all loads in flight together
       constexpr int GROUP = 4;                      // 4 rounds x (3-4 loads) in flight; 7 rounds cost 60 more VGPRs and a wave per SIMD
@@ -246,18 +250,20 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
                const double dfi = (STEP == 3) ? a.dfEmbed[(size_t)iBox * a.cap + i] : 0.0;
                int qn = 0;
                for (int t = 0; t < nTiles; ++t) {
-                  {
-                     const int c = t * 64 + lane;
-                     const int cc = c < nCand ? c : 0;                  // lanes past the list re-read candidate 0 and are masked
-                     const double dx = xi - sx[cc], dy = yi - sy[cc], dz = zi - sz[cc];
-                     const double r2 = dx*dx + dy*dy + dz*dz;
-                     const bool hit = (r2 <= a.rc2) && (r2 > 0.0) && (c < nCand);
-                     const unsigned long long m = __ballot(hit);
-                     if (hit) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)(t * 64 + lane);
-                     qn += __popcll(m);
-                  }
+                  const int c = t * 64 + lane;
+                  const int cc = c < nCand ? c : 0;                  // lanes past the list re-read candidate 0 and are masked
+                  const double dx = xi - sx[cc], dy = yi - sy[cc], dz = zi - sz[cc];
+                  const double r2 = dx*dx + dy*dy + dz*dz;
+                  const bool hit = (r2 <= a.rc2) && (r2 > 0.0) && (c < nCand);
+                  const unsigned long long m = __ballot(hit);
+                  if (hit) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)(t * 64 + lane);
+                  qn += __popcll(m);
                }
-               // accepted pairs: 64 per batch (one batch for FCC Cu: 42 neighbours inside the cutoff)
+               // More neighbours inside the cutoff than the queue holds (3x FCC Cu): the excess went into the next queue / past
+               // the LDS allocation (dropped by the hardware); the results are void, the flag makes comdCheckStatus stop the run.
+               // (reported once, after the cell walk: a store in here costs 4 % -- the loads behind it lose their freedom to move)
+               if (qn > EAM_CTA_QUEUE) { overrun = 1; qn = EAM_CTA_QUEUE; }
+               // accepted pairs, 64 per batch (FCC Cu: 42 neighbours inside the Cu_u6 cutoff, 54 inside Mishin's -> one batch)
                for (int b = 0; b < qn; b += 64) {
                   if (b + lane < qn) {
                      const int jj = q[b + lane];
@@ -295,11 +301,13 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
       }
       __builtin_amdgcn_wave_barrier();
    }
+   if (overrun && lane == 0) atomicOr(&status[3], 1);
 }
 
-static inline size_t eamCtaLdsBytes(int step, int nRho, int nPhi)
+static inline size_t eamCtaTableBytes(int step, int nRho, int nPhi) { return (size_t)(nRho + 3 + (step == 1 ? nPhi + 3 : 0)) * 8; }
+
+static inline size_t eamCtaLdsBytes(int step, int maxCand, size_t tableBytes)
 {
-   size_t tables = (size_t)(nRho + 3 + (step == 1 ? nPhi + 3 : 0)) * 8;
-   size_t perWave = (size_t)3 * EAM_CTA_MAXCAND * 8 + (step == 3 ? EAM_CTA_MAXCAND * 4 : 0) + 2 * EAM_CTA_QUEUE * 2 + 64 * 4;
-   return tables + EAM_CTA_WAVES * perWave;
+   size_t perWave = (size_t)3 * maxCand * 8 + (step == 3 ? maxCand * 4 : 0) + 2 * EAM_CTA_QUEUE * 2 + 64 * 4;
+   return tableBytes + EAM_CTA_WAVES * perWave;
 }

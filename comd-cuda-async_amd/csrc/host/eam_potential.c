@@ -90,6 +90,47 @@ static void eamReadFuncfl(EamPotential* pot, const char* dir, const char* potNam
    fclose(fp);
 }
 
+/* setfl (eam.c:680-757), one element: 3 comment lines, "ntypes ...", "nRho dRho nR dR cutoff", "Z mass lat lattice", then F(rho),
+ * rho(r) and r*phi(r) (converted to phi, phi[0] extrapolated). */
+static void eamReadSetfl(EamPotential* pot, const char* dir, const char* potName)
+{
+   char tmp[4096];
+   snprintf(tmp, sizeof tmp, "%s/%s", dir, potName);
+   FILE* fp = fopen(tmp, "r");
+   if (!fp) fileNotFound("eamReadSetfl", tmp);
+   for (int i = 0; i < 3; ++i) if (!fgets(tmp, sizeof tmp, fp)) fileNotFound("eamReadSetfl", potName);
+   int nElems = 0;
+   if (!fgets(tmp, sizeof tmp, fp)) fileNotFound("eamReadSetfl", potName);
+   sscanf(tmp, "%d", &nElems);
+   if (nElems != 1) {
+      fprintf(screenOut, "eamReadSetfl: CoMD 1.1 does not support alloys and cannot\n   read setfl files with multiple species.  Fatal Error.\n");
+      exit(-1);
+   }
+   int nRho, nR; double dRho, dR, cutoff;
+   if (!fgets(tmp, sizeof tmp, fp)) fileNotFound("eamReadSetfl", potName);
+   sscanf(tmp, "%d %le %d %le %le", &nRho, &dRho, &nR, &dR, &cutoff);
+   pot->cutoff = cutoff;
+   int nAtomic; double mass, lat; char latticeType[8];
+   if (!fgets(tmp, sizeof tmp, fp)) fileNotFound("eamReadSetfl", potName);
+   sscanf(tmp, "%d %le %le %7s", &nAtomic, &mass, &lat, latticeType);
+   pot->atomicNo = nAtomic; pot->lat = lat; pot->mass = mass * amuToInternalMass;
+   strcpy(pot->latticeType, latticeType);
+   strcpy(pot->name, "Cu");                     /* the reference leaves name unset for setfl; the only shipped file is Cu */
+   const real_t x0 = 0.0;
+   int bufSize = nRho > nR ? nRho : nR;
+   real_t* buf = (real_t*)malloc((size_t)bufSize * sizeof(real_t));
+   for (int i = 0; i < nRho; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadSetfl(F)", potName);
+   pot->f = initInterpolationObject(nRho, x0, dRho, buf);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadSetfl(rho)", potName);
+   pot->rho = initInterpolationObject(nR, x0, dR, buf);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadSetfl(phi)", potName);
+   for (int i = 1; i < nR; ++i) buf[i] /= (x0 + i * dR);
+   buf[0] = buf[1] + (buf[1] - buf[2]);
+   pot->phi = initInterpolationObject(nR, x0, dR, buf);
+   free(buf);
+   fclose(fp);
+}
+
 BasePotential* initEamPot(const char* dir, const char* file, const char* type)
 {
    EamPotential* pot = (EamPotential*)calloc(1, sizeof(EamPotential));
@@ -98,8 +139,9 @@ BasePotential* initEamPot(const char* dir, const char* file, const char* type)
    pot->destroy = eamDestroy;
    /* every rank reads the (36 kB) file itself; the reference reads on rank 0 and broadcasts (eam.c:160-171) */
    if (strcmp(type, "funcfl") == 0) eamReadFuncfl(pot, dir, file);
+   else if (strcmp(type, "setfl") == 0) eamReadSetfl(pot, dir, file);
    else {
-      fprintf(screenOut, "initEamPot: Potential type %s not supported. Fatal Error.\n", type);   /* setfl: SURVEY 8f */
+      fprintf(screenOut, "initEamPot: Potential type %s not supported. Fatal Error.\n", type);
       exit(-1);
    }
    return (BasePotential*)pot;

@@ -91,7 +91,7 @@ typedef struct SimGpu {
    /* redistribution scratch (CoMDTypes.h:123-126 flags/tmp_sort) */
    int*         nAtomsPrev;            /* device [nTotalBoxes]: occupancy snapshot */
    int*         cellDirty;             /* device [nTotalBoxes]: membership changed, needs compaction + gid sort */
-   int*         status;                /* device [4]: {cell overflow, lost atom, msg overflow, spare} */
+   int*         status;                /* device [4]: {cell overflow, lost atom, msg overflow, EAM pair-queue overflow} */
    real_t*      reduceBuf;             /* device: per-block partial sums for computeEnergy */
    real_t*      pinned;                /* pinned host staging (energies, counts) */
    int          reduceBlocks;

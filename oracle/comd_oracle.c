@@ -265,6 +265,35 @@ static int readFuncfl(OracleSim* s, const char* dir, const char* name)
    return 0;
 }
 
+/* ---- eam.c:680-757 eamReadSetfl (single element) ------------------------------------------ */
+static int readSetfl(OracleSim* s, const char* dir, const char* name)
+{
+   char path[4096], line[4096];
+   snprintf(path, sizeof path, "%s/%s", dir, name);
+   FILE* fp = fopen(path, "r");
+   if (!fp) { fprintf(stderr, "oracle: cannot open %s\n", path); return -1; }
+   for (int i = 0; i < 3; ++i) if (!fgets(line, sizeof line, fp)) { fclose(fp); return -1; }      /* comments */
+   int nElems = 0;
+   if (!fgets(line, sizeof line, fp) || sscanf(line, "%d", &nElems) != 1 || nElems != 1) { fclose(fp); return -1; }
+   int nRho, nR; double dRho, dR, rc;
+   if (!fgets(line, sizeof line, fp) || sscanf(line, "%d %le %d %le %le", &nRho, &dRho, &nR, &dR, &rc) != 5) { fclose(fp); return -1; }
+   int z; double amu, lat; char ltype[16];
+   if (!fgets(line, sizeof line, fp) || sscanf(line, "%d %le %le %15s", &z, &amu, &lat, ltype) != 4) { fclose(fp); return -1; }
+   s->lat = lat; s->mass = amu * kAmuToInternalMass; s->cutoff = rc;
+   int nb = nRho > nR ? nRho : nR;
+   double* buf = (double*)malloc((size_t)nb * sizeof(double));
+   for (int i = 0; i < nRho; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   tableInit(&s->F, nRho, 0.0, dRho, buf);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   tableInit(&s->rho, nR, 0.0, dR, buf);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   for (int i = 1; i < nR; ++i) buf[i] /= (0.0 + i * dR);          /* the file stores r * phi(r) */
+   buf[0] = buf[1] + (buf[1] - buf[2]);
+   tableInit(&s->phi, nR, 0.0, dR, buf);
+   free(buf); fclose(fp);
+   return 0;
+}
+
 /* ---- timestep.c:109-133 kineticEnergy (sum over virtual ranks = addRealParallel) -------- */
 void oracle_kinetic_energy(OracleSim* s)
 {
@@ -702,7 +731,10 @@ OracleSim* oracle_create(int nx, int ny, int nz, int px, int py, int pz,
    s->nx = nx; s->ny = ny; s->nz = nz; s->pg[0] = px; s->pg[1] = py; s->pg[2] = pz;
    s->nRanks = px * py * pz; s->doeam = doeam; s->dt = dt;
    if (doeam) {
-      if (readFuncfl(s, potDir, potName) != 0) { free(s); return NULL; }
+      /* potType is carried by the file name here: *.alloy = setfl (mycommand.c:286-291 default names) */
+      size_t ln = strlen(potName);
+      int isSetfl = ln > 6 && strcmp(potName + ln - 6, ".alloy") == 0;
+      if ((isSetfl ? readSetfl(s, potDir, potName) : readFuncfl(s, potDir, potName)) != 0) { free(s); return NULL; }
    } else {                                        /* ljForce.c:102-120 */
       s->sigma = 2.315; s->epsilon = 0.167; s->mass = 63.55 * kAmuToInternalMass;
       s->lat = 3.615; s->cutoff = 5 * s->sigma;

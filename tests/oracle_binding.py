@@ -63,11 +63,11 @@ def lib():
 class Oracle:
     """CPU restatement of the reference path; all ranks of the decomposition live in this process."""
 
-    def __init__(self, n, procs=(1, 1, 1), eam=0, temperature=600.0, delta=0.0, dt=1.0, cap=0, lat=-1.0):
+    def __init__(self, n, procs=(1, 1, 1), eam=0, temperature=600.0, delta=0.0, dt=1.0, cap=0, lat=-1.0, pot_name="Cu_u6.eam"):
         self.L = lib()
         nx, ny, nz = (n, n, n) if isinstance(n, int) else n
         self.ptr = self.L.oracle_create(nx, ny, nz, procs[0], procs[1], procs[2], lat, eam,
-                                        POT_DIR.encode(), b"Cu_u6.eam", temperature, delta, dt, cap)
+                                        POT_DIR.encode(), pot_name.encode(), temperature, delta, dt, cap)
         if not self.ptr:
             raise RuntimeError("oracle_create failed")
         self.n_global = self.L.oracle_n_global(self.ptr)

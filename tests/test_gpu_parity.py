@@ -100,6 +100,33 @@ def test_eam_cohesive_energy(gpu):
         assert abs(_per_atom(sim)[1] - G["repo_native"]["eam_adams_cohesive_energy"]["value"]) < TOL["energy_per_atom_step0"]
 
 
+SETFL = ["-t", "setfl", "-p", "Cu01.eam.alloy"]
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_setfl_cohesive_energy(gpu, method):
+    """CoMD.c:899: perfect lattice under Mishin's Cu01.eam.alloy (setfl, 10000-sample tables, cutoff 5.507 A): -3.539999969176."""
+    ref = G["repo_native"]["eam_mishin_cohesive_energy"]
+    with gpu.Simulation(_args(10, 1, 0.0, method, ["-T", 0] + SETFL)) as sim:
+        assert abs(_per_atom(sim)[1] - ref["value"]) < ref["tolerance"]
+
+
+@pytest.mark.parametrize("method", METHODS)
+def test_setfl_forces_match_oracle(gpu, orc, method):
+    """setfl tables are too large for the LDS: cta_cell reads them through L2 and stages up to 640 stencil atoms per wave."""
+    n = (8, 9, 10)
+    with gpu.Simulation(_args(n, 1, 0.12, method, SETFL)) as sim:
+        o = orc.Oracle(n, eam=1, delta=0.12, cap=max(sim.max_atoms, 64), pot_name="Cu01.eam.alloy")
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < 1e-12
+        sim.step(20)
+        o.step(20)
+        (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
+        assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
+
+
 @pytest.mark.parametrize("eam,n", [(0, 12), (1, 9)])
 def test_trajectory_tracks_oracle(gpu, orc, eam, n):
     """25 steps from a displaced lattice: positions, momenta and forces stay together atom by atom."""

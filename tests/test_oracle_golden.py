@@ -120,3 +120,12 @@ def test_migration_across_ranks_conserves_atoms(orc):
     assert np.all(seen == 1)
     assert abs(o.energy()[0] - u0) < 1e-11 * abs(u0)
     assert np.abs(o.gather(orc.F) - f0).max() < 1e-10 * np.abs(f0).max()
+
+
+def test_setfl_mishin_cohesive_energy(orc):
+    """CoMD.c:899: the Mishin Cu01.eam.alloy (setfl) perfect-lattice energy, -3.539999969176 eV/atom."""
+    ref = G["repo_native"]["eam_mishin_cohesive_energy"]
+    o = orc.Oracle(8, eam=1, temperature=0.0, pot_name="Cu01.eam.alloy")
+    ep, ek = o.energy()
+    assert ek == 0.0
+    assert abs(ep / o.n_global - ref["value"]) < ref["tolerance"]
