@@ -374,6 +374,7 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       const int tablesInLds = tableBytes <= 32 * 1024;
       int grid = ceilDiv(num_cells, EAM_CTA_WAVES);
       if (grid > 2048) grid = 2048;             // persistent: 8 workgroups per CU's worth, each wave strides over cells
+      if (grid < 8) grid = 8;                   // the kernel deals cell ranges to XCDs (blockIdx % 8): every XCD needs a workgroup
       if (tablesInLds) {
          const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, tableBytes);
          static bool attrSet = false;

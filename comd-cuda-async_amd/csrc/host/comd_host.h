@@ -44,6 +44,7 @@ void printCmdYaml(FILE* file, Command* cmd);
 
 void initParallel(int rank, int nRanks, const CommTransport* transport);   /* parallel.c:57-64 */
 void destroyParallel(void);
+int  loopbackParallel(void);
 int  getNRanks(void);
 int  getMyRank(void);
 int  printRank(void);

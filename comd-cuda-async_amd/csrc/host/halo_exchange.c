@@ -258,7 +258,7 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
    int nSendP = hh->loadBuffer(hh->parms, data, faceP, hh->sendBufP);
    const int nbrM = hh->nbrRank[faceM], nbrP = hh->nbrRank[faceP];
 
-   if (nbrM == getMyRank() && nbrP == getMyRank()) {
+   if (nbrM == getMyRank() && nbrP == getMyRank() && !loopbackParallel()) {
       /* this rank is its own neighbour along the axis: what it sends through the minus face arrives through its plus
        * face.  Unpack straight from the send buffers (the reference's comm path has the same shortcut, haloExchange.c:788-853). */
       hh->unloadBuffer(hh->parms, data, faceM, nSendP, hh->sendBufP);

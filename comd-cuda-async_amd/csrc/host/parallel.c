@@ -12,24 +12,30 @@ static int myRank = 0;
 static int nRanks = 1;
 static CommTransport transport;
 static int haveTransport = 0;
+static int loopback = 0;        /* one rank that still talks through its transport (to itself): COMD_LOOPBACK_TRANSPORT=1 */
 
 void initParallel(int rank, int n, const CommTransport* t)
 {
    myRank = rank; nRanks = n;
    haveTransport = 0;
    if (t) { transport = *t; haveTransport = 1; }
+   const char* lb = getenv("COMD_LOOPBACK_TRANSPORT");
+   loopback = haveTransport && nRanks == 1 && lb && atoi(lb) != 0;
    if (nRanks > 1 && !haveTransport) {
       fprintf(stderr, "initParallel: %d ranks need a transport\n", nRanks);
       exit(-1);
    }
 }
 
-void destroyParallel(void) { haveTransport = 0; myRank = 0; nRanks = 1; }
+void destroyParallel(void) { haveTransport = 0; loopback = 0; myRank = 0; nRanks = 1; }
+
+/* every message, reduction and broadcast goes through the transport even on one rank (exercises RCCL on a one-GPU box) */
+int loopbackParallel(void) { return loopback; }
 int getNRanks(void) { return nRanks; }
 int getMyRank(void) { return myRank; }
 int printRank(void) { return myRank == 0; }
 
-void barrierParallel(void) { if (nRanks > 1) transport.barrier(transport.ctx); }
+void barrierParallel(void) { if (nRanks > 1 || loopback) transport.barrier(transport.ctx); }
 
 void timestampBarrier(const char* msg)
 {
@@ -52,7 +58,7 @@ int sendReceiveParallel(void* sendBuf, int sendLen, int dest, void* recvBuf, int
 /* device buffers, ordered on `stream` */
 int sendReceiveDevice(void* sendBuf, int sendLen, int dest, void* recvBuf, int recvLen, int source, comdStream_t stream)
 {
-   if (nRanks == 1) { comdMemcpyDtoDAsync(recvBuf, sendBuf, sendLen, stream); return sendLen; }
+   if (nRanks == 1 && !loopback) { comdMemcpyDtoDAsync(recvBuf, sendBuf, sendLen, stream); return sendLen; }
    return transport.sendrecv(transport.ctx, sendBuf, sendLen, dest, recvBuf, recvLen, source, 1, stream);
 }
 
@@ -60,7 +66,7 @@ int sendReceiveDevice(void* sendBuf, int sendLen, int dest, void* recvBuf, int r
 void sendReceiveDevice2(void* sendM, int nSendM, int dstM, void* recvP, void* sendP, int nSendP, int dstP, void* recvM,
                         int recvCap, comdStream_t stream, int nRecv[2])
 {
-   if (haveTransport && transport.sendrecv2) {
+   if (haveTransport && transport.sendrecv2 && (nRanks > 1 || loopback)) {
       transport.sendrecv2(transport.ctx, sendM, nSendM, dstM, recvP, sendP, nSendP, dstP, recvM, recvCap, 1, stream, nRecv);
       return;
    }
@@ -71,13 +77,13 @@ void sendReceiveDevice2(void* sendM, int nSendM, int dstM, void* recvP, void* se
 void addIntParallel(int* sendBuf, int* recvBuf, int count)
 {
    memmove(recvBuf, sendBuf, (size_t)count * sizeof(int));
-   if (nRanks > 1) transport.allreduce(transport.ctx, recvBuf, count, 0);
+   if (nRanks > 1 || loopback) transport.allreduce(transport.ctx, recvBuf, count, 0);
 }
 
 void addRealParallel(real_t* sendBuf, real_t* recvBuf, int count)
 {
    memmove(recvBuf, sendBuf, (size_t)count * sizeof(real_t));
-   if (nRanks > 1) transport.allreduce(transport.ctx, recvBuf, count, 1);
+   if (nRanks > 1 || loopback) transport.allreduce(transport.ctx, recvBuf, count, 1);
 }
 
 void addDoubleParallel(double* sendBuf, double* recvBuf, int count) { addRealParallel(sendBuf, recvBuf, count); }
@@ -85,7 +91,7 @@ void addDoubleParallel(double* sendBuf, double* recvBuf, int count) { addRealPar
 void maxIntParallel(int* sendBuf, int* recvBuf, int count)
 {
    memmove(recvBuf, sendBuf, (size_t)count * sizeof(int));
-   if (nRanks > 1) transport.allreduce(transport.ctx, recvBuf, count, 2);
+   if (nRanks > 1 || loopback) transport.allreduce(transport.ctx, recvBuf, count, 2);
 }
 
-void bcastParallel(void* buf, int len, int root) { if (nRanks > 1) transport.bcast(transport.ctx, buf, len, root); }
+void bcastParallel(void* buf, int len, int root) { if (nRanks > 1 || loopback) transport.bcast(transport.ctx, buf, len, root); }

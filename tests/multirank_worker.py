@@ -134,8 +134,36 @@ def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async):
     sim.close()
 
 
+def rccl_loopback_mode(pkg, orc, eam, n, method, use_async):
+    """One rank whose halo messages, reductions and broadcasts all go through the RCCL transport (ncclSend/ncclRecv to itself):
+    the only way to run comm_rccl.hip on a one-GPU box.  COMD_LOOPBACK_TRANSPORT=1 is set by the launcher."""
+    pkg.setup_gpu(0, 0)
+    t = pkg.rccl_transport(0, 1, pkg.rccl_unique_id())
+    pkg.init_parallel(0, 1, t)
+    assert pkg.lib_host().loopbackParallel() == 1
+    args = ["-x", n, "-y", n, "-z", n, "-r", 0.1, "-m", method, "-a", use_async] + (["-e"] if eam else [])
+    sim = pkg.Simulation(args)
+    o = orc.Oracle(n, eam=eam, delta=0.1)
+    fo = o.gather(orc.F)
+    assert np.abs(sim.gather(2) - fo).max() < 1e-11 * np.abs(fo).max()
+    sim.step(12)
+    o.step(12)
+    e1, eo, fo = sim.energy(), o.energy(), o.gather(orc.F)
+    assert np.abs(sim.gather(2) - fo).max() < 1e-9 * np.abs(fo).max()
+    assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < 2e-12
+    sim.sum_atoms()
+    assert sim.energy()[2] == 4 * n ** 3
+    sim.close()
+    pkg.lib_hip().comdCommFinalize()
+    print(f"rccl-loopback OK: {'EAM' if eam else 'LJ'} {n}^3 {method} async={use_async}: E/atom {(e1[0]+e1[1])/e1[2]:.12f}")
+
+
 def main():
     mode, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    if mode == "rccl":
+        pkg, orc = ge.load_package(), ge.load_oracle()
+        rccl_loopback_mode(pkg, orc, int(sys.argv[8]), int(sys.argv[9]), sys.argv[10], int(sys.argv[11]))
+        return
     grid = tuple(int(v) for v in sys.argv[5:8])
     eam, n = int(sys.argv[8]), int(sys.argv[9])
     method = sys.argv[10] if len(sys.argv) > 10 else "thread_atom"

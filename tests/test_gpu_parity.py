@@ -46,6 +46,20 @@ def test_forces_match_oracle(gpu, orc, method, eam, n, delta):
             assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < 1e-12
 
 
+@pytest.mark.parametrize("eam,n,method", [(1, 10, "cta_cell"), (1, 10, "thread_atom"), (0, 14, "cta_cell"), (0, 14, "thread_atom")])
+def test_overlap_mode_small_interior(gpu, orc, eam, n, method):
+    """-a 1 on one rank: interior cells (27 for EAM 10^3, 8 for LJ 14^3) on one stream, the two boundary rings on the other.
+    Small interior lists are launches of fewer than 8 workgroups -- the XCD-dealt cell walk must still cover every cell."""
+    with gpu.Simulation(_args(n, eam, 0.1, method, ["-a", 1])) as sim:
+        o = orc.Oracle(n, eam=eam, delta=0.1, cap=max(sim.max_atoms, 64))
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
+        sim.step(10)
+        o.step(10)
+        (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
+        assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
+
+
 def test_lj_cells_larger_than_the_launch_estimate(gpu, orc, monkeypatch):
     """thread_atom sizes its workgroups from the host's last occupancy reading; a cell that outgrew it must still be complete.
     Forcing one wave per cell makes every cell take the extra-chunk path (chunks 1 and 2 through the generic per-lane code)."""

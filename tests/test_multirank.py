@@ -21,10 +21,10 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(mode, grid, eam, n, extra=(), timeout=600):
+def _launch(mode, grid, eam, n, extra=(), timeout=600, env_extra=None):
     world = grid[0] * grid[1] * grid[2]
     port = str(_free_port())
-    env = dict(os.environ, OMP_NUM_THREADS="2")
+    env = dict(os.environ, OMP_NUM_THREADS="2", **(env_extra or {}))
     procs = [subprocess.Popen([sys.executable, os.path.join(HERE, "multirank_worker.py"), mode, str(r), str(world), port,
                                *map(str, grid), str(eam), str(n), *map(str, extra)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
@@ -54,3 +54,12 @@ def test_host_logic_two_processes_gloo(grid, eam, n):
 def test_gpu_path_multi_rank_shared_device(grid, eam, n, method, use_async):
     outs = _launch("gpu", grid, eam, n, extra=(method, use_async))
     assert "gpu-mode OK" in outs[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eam,n,method,use_async", [(0, 14, "thread_atom", 0), (1, 10, "cta_cell", 1)])
+def test_rccl_transport_loopback(eam, n, method, use_async):
+    """comm_rccl.hip on real hardware: a one-rank RCCL communicator carries all six halo messages per exchange (size handshake +
+    grouped ncclSend/ncclRecv to itself), the EAM dF/drho exchange and the energy / atom-count reductions."""
+    outs = _launch("rccl", (1, 1, 1), eam, n, extra=(method, use_async), env_extra={"COMD_LOOPBACK_TRANSPORT": "1"})
+    assert "rccl-loopback OK" in outs[0]
