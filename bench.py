@@ -102,15 +102,20 @@ def main():
     px, py, pz = GRIDS[a.gpus]
     use_async = a.async_halo if a.async_halo is not None else (1 if a.gpus > 1 else 0)
 
-    pkg = ge.load_package()
+    # One GPU can rehearse the multi-GPU code path: COMD_LOOPBACK_TRANSPORT=1 sends every halo message and reduction of the
+    # single rank through RCCL (to itself), with the same library load order and rendezvous as a torch.distributed.run launch.
+    loopback = world == 1 and os.environ.get("COMD_LOOPBACK_TRANSPORT", "0") not in ("", "0")
     dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group("gloo")                     # control plane only; halo data moves over RCCL
+    if world > 1 or loopback:
+        import torch.distributed as dist                    # torch first: its bundled HIP/RCCL runtime is the one both sides share
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; halo data moves over RCCL
+    pkg = ge.load_package()
     if "COMD_FORCE_DEVICE" in os.environ:               # debugging aid: several ranks on one GPU
         local_rank = int(os.environ["COMD_FORCE_DEVICE"])
     pkg.setup_gpu(local_rank, rank, verbose=(rank == 0))
-    if world > 1:
+    if dist is not None:
         ids = [pkg.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         transport = pkg.rccl_transport(rank, world, ids[0])
@@ -165,7 +170,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.pot.upper()} Cu FCC {a.nx}^3 unit cells per GPU ({int(n_local)} atoms/GPU, {n_global} total), "
                                    f"{method} kernel, fp64, T=600 K, dt=1 fs",
-                       "decomposition": f"{px}x{py}x{pz}", "halo_overlap": bool(use_async), "cell_capacity": sim.max_atoms},
+                       "decomposition": f"{px}x{py}x{pz}", "halo_overlap": bool(use_async), "cell_capacity": sim.max_atoms,
+                       **({"transport": "rccl-loopback"} if loopback else {})},
             "per_gpu_value": value / a.gpus,
             "energy_per_atom_eV": (ep + ek) / n_global,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
