@@ -103,6 +103,8 @@ def lib_host():
         lib.comdHostAtoms.argtypes = [vp]
         lib.comdHostAtoms.restype = ctypes.POINTER(HostAtoms)
         lib.comdGridInfo.argtypes = [vp, c_int_p]
+        lib.comdNeighborListBuilds.argtypes = [vp]
+        lib.comdNeighborListBuilds.restype = ctypes.c_int
         lib.comdSimBoxFromTuple.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
         lib.comdSimBoxFromCoord.argtypes = [vp, c_double_p]
         lib.comdFaceCells.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
@@ -191,6 +193,11 @@ class Simulation:
 
     def compute_force(self):
         self.lib.computeForce(self.ptr)
+
+    @property
+    def nl_builds(self):
+        """Verlet-list builds so far (thread_atom_nl)."""
+        return self.lib.comdNeighborListBuilds(self.ptr)
 
     def kinetic_energy(self):
         self.lib.kineticEnergyGpu(self.ptr)

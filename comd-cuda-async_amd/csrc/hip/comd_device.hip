@@ -13,6 +13,7 @@
 #include "lj_kernels.h"
 #include "eam_kernels.h"
 #include "step_kernels.h"
+#include "nl_kernels.h"
 
 static int g_rank = 0;
 
@@ -171,6 +172,26 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
       sim->eam_pot.rhobar = dalloc<real_t>(slots);
       sim->eam_pot.dfEmbed = dalloc<real_t>(slots);
    }
+   if (cfg->skinDistance > 0.0) {               // gpu_neighborList.c:49-86 initNeighborListGpu
+      NeighborListGpu* nl = &at->neighborList;
+      const real_t cutoff = cfg->do_eam ? cfg->eamCutoff : cfg->ljCutoff;
+      nl->skinDistance = cfg->skinDistance; nl->skinDistance2 = cfg->skinDistance * cfg->skinDistance;
+      nl->skinDistanceHalf2 = 0.25 * nl->skinDistance2;
+      nl->maxNeighbors = cfg->maxNeighbors;
+      if (nl->maxNeighbors <= 0) {
+         // atoms inside the list sphere at the perfect-lattice density (4 per lat^3), + 20 % and 24 for thermal crowding
+         const double rl = cutoff + cfg->skinDistance, lat = cfg->latticeConstant > 0.0 ? cfg->latticeConstant : 3.615;
+         const double expect = 4.0 / (lat * lat * lat) * 4.18879020478639 * rl * rl * rl;
+         nl->maxNeighbors = ((int)(1.2 * expect) + 24 + 7) / 8 * 8;
+      }
+      if (nl->maxNeighbors > 27 * cfg->maxAtoms) nl->maxNeighbors = 27 * cfg->maxAtoms;
+      const size_t localSlots = (size_t)cfg->nLocalBoxes * cfg->maxAtoms;
+      nl->list = dalloc<int>(localSlots * nl->maxNeighbors, false);
+      nl->nNeighbors = dalloc<int>(localSlots);
+      nl->lastR.x = dalloc<real_t>(localSlots); nl->lastR.y = dalloc<real_t>(localSlots); nl->lastR.z = dalloc<real_t>(localSlots);
+      nl->updateRequired = dalloc<int>(1);
+      nl->forceRebuildFlag = 1; nl->nBuilds = 0;
+   }
    sim->nAtomsPrev = dalloc<int>(cfg->nTotalBoxes);
    sim->cellDirty = dalloc<int>(cfg->nTotalBoxes);
    sim->status = dalloc<int>(4);
@@ -247,7 +268,9 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.e, sim->atoms.iSpecies, sim->atoms.gid,
                     sim->neighbor_cells, sim->species_mass, sim->eam_pot.phi.values, sim->eam_pot.rho.values, sim->eam_pot.f.values,
                     sim->eam_pot.rhobar, sim->eam_pot.dfEmbed, sim->nAtomsPrev, sim->cellDirty, sim->status, sim->reduceBuf,
-                    sim->boundary_cells, sim->interior_cells, sim->boundary1_cells };
+                    sim->boundary_cells, sim->interior_cells, sim->boundary1_cells,
+                    sim->atoms.neighborList.list, sim->atoms.neighborList.nNeighbors, sim->atoms.neighborList.lastR.x,
+                    sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
@@ -272,7 +295,8 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
       if (st[0] & 2) fprintf(stderr, "a cell stencil holds more atoms than the cta_cell kernel can stage; ");
       if (st[1])     fprintf(stderr, "an atom moved beyond the halo region and was lost; ");
       if (st[2])     fprintf(stderr, "a halo message overflowed its buffer; ");
-      if (st[3])     fprintf(stderr, "an atom has more neighbours inside the cutoff than the EAM cta_cell pair queue holds (use -m thread_atom); ");
+      if (st[3] & 1) fprintf(stderr, "an atom has more neighbours inside the cutoff than the EAM cta_cell pair queue holds (use -m thread_atom); ");
+      if (st[3] & 2) fprintf(stderr, "an atom has more than %d neighbours inside cutoff + skin (raise --maxNeighbors); ", sim->atoms.neighborList.maxNeighbors);
       fprintf(stderr, "\n");
       exit(-1);
    }
@@ -287,6 +311,15 @@ extern "C" int comdReadDeviceInt(const int* d_ptr, comdStream_t stream)
 }
 
 // ---- force -------------------------------------------------------------------------------------------------------
+static NlView nlView(SimGpu* sim)
+{
+   NeighborListGpu* n = &sim->atoms.neighborList;
+   if (!n->list) { fprintf(stderr, "the *_nl methods need Verlet lists: allocate with GpuConfig.skinDistance > 0\n"); exit(-1); }
+   if (n->nBuilds == 0) { fprintf(stderr, "the *_nl methods need buildNeighborListGpu before the first force call\n"); exit(-1); }
+   NlView v; v.list = n->list; v.count = n->nNeighbors; v.maxNbr = n->maxNeighbors;
+   return v;
+}
+
 static LjArgs makeLjArgs(SimGpu* sim, int num_cells, int* cells_list)
 {
    LjArgs a;
@@ -313,7 +346,12 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
    if (num_cells <= 0) return;
    LjArgs a = makeLjArgs(sim, num_cells, cells_list);
    ForceTimer timer(S(stream));
-   if (method == CTA_CELL) {
+   if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
+      const NlView nl = nlView(sim);
+      const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
+      if (g_needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom_nl<true>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
+      else              hipLaunchKernelGGL(LJ_Force_thread_atom_nl<false>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
+   } else if (method == CTA_CELL) {
       const size_t lds = ljCtaLdsBytes(sim->maxAtoms);
       static size_t attrSet = 0;
       if (lds > attrSet) {
@@ -367,7 +405,13 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
    if (num_cells <= 0) return;
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
    ForceTimer timer(st);
-   if (method == CTA_CELL) {
+   if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
+      const NlView nl = nlView(sim);
+      const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
+      const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
+      if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
+      else                         hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
+   } else if (method == CTA_CELL) {
       // funcfl tables (500 samples) live in the LDS; setfl tables (10000 samples, 80 KB each) stay in L2 and the LDS
       // goes to a wider candidate list instead (longer cutoff -> more atoms per stencil)
       const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
@@ -571,8 +615,56 @@ extern "C" void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d
    LAUNCH_CHECK();
 }
 
-// ---- neighbour-list bookkeeping: out of scope, link-compatible no-ops ---------------------------------------------------
-extern "C" void emptyNeighborListGpu(SimGpu*, int) {}
-extern "C" int  neighborListUpdateRequiredGpu(SimGpu*) { return 1; }
-extern "C" int  pairlistUpdateRequiredGpu(SimGpu*) { return 1; }
-extern "C" void buildNeighborListGpu(SimGpu*, int, int) {}
+// ---- Verlet neighbour lists ------------------------------------------------------------------------------------------------
+extern "C" void emptyNeighborListGpu(SimGpu* sim, int)
+{
+   NeighborListGpu* n = &sim->atoms.neighborList;
+   if (n->nNeighbors) HIP_CHECK(hipMemsetAsync(n->nNeighbors, 0, (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * sizeof(int), S(sim->boundary_stream)));
+}
+
+extern "C" void neighborListForceRebuildGpu(SimGpu* sim) { sim->atoms.neighborList.forceRebuildFlag = 1; }
+
+extern "C" int neighborListUpdateRequiredGpu(SimGpu* sim)
+{
+   NeighborListGpu* n = &sim->atoms.neighborList;
+   if (!n->list || n->forceRebuildFlag) return 1;
+   hipStream_t st = S(sim->boundary_stream);
+   HIP_CHECK(hipMemsetAsync(n->updateRequired, 0, sizeof(int), st));
+   hipLaunchKernelGGL(NeighborListUpdateRequired, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, n->lastR.x, n->lastR.y, n->lastR.z,
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, n->skinDistanceHalf2, n->updateRequired);
+   LAUNCH_CHECK();
+   return comdReadDeviceInt(n->updateRequired, sim->boundary_stream);
+}
+
+extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
+{
+   (void)method; (void)boundaryFlag;
+   NeighborListGpu* n = &sim->atoms.neighborList;
+   if (!n->list) { fprintf(stderr, "buildNeighborListGpu: no lists allocated (GpuConfig.skinDistance == 0)\n"); exit(-1); }
+   const real_t cutoff = sim->do_eam ? sim->eam_pot.cutoff : sim->lj_pot.cutoff;
+   const real_t rBuild = cutoff + n->skinDistance;
+   NlView v; v.list = n->list; v.count = n->nNeighbors; v.maxNbr = n->maxNeighbors;
+   hipLaunchKernelGGL(BuildNeighborList, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, S(sim->boundary_stream),
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells, (const int*)nullptr,
+                      sim->boxes.nLocalBoxes, sim->maxAtoms, v, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, sim->status);
+   LAUNCH_CHECK();
+   n->forceRebuildFlag = 0;
+   n->nBuilds++;
+}
+
+extern "C" int pairlistUpdateRequiredGpu(SimGpu*) { return 1; }
+
+extern "C" void loadPositionBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, const real_t shift[3], SimGpu* sim, comdStream_t stream)
+{
+   hipLaunchKernelGGL(LoadPositionBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, S(stream), gpu_buf, d_cellList, d_cellOffsets,
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->maxAtoms, shift[0], shift[1], shift[2]);
+   LAUNCH_CHECK();
+}
+
+extern "C" void unloadPositionBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
+{
+   hipLaunchKernelGGL(UnloadPositionBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, S(stream), gpu_buf, d_cellList, d_cellOffsets,
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->maxAtoms);
+   LAUNCH_CHECK();
+}

@@ -1,7 +1,8 @@
 /* cli.c -- the CoMD command line (mycommand.c:180-320 + cmdLineParser.c): same long names, same single-letter
  * flags, same defaults, same "Command Line Parameters" YAML block.  Table-driven over getopt_long.
  * Extensions (long options only): --maxAtoms N (link-cell slot capacity; the reference fixes it at
- * compile time with -DMAXATOMS), --quiet. */
+ * compile time with -DMAXATOMS), --maxNeighbors N (Verlet-list rows per atom for the *_nl methods; the reference's
+ * MAXNEIGHBORLISTSIZE), --quiet. */
 #include "comd_host.h"
 #include <getopt.h>
 #include <stdlib.h>
@@ -53,13 +54,14 @@ Command parseCommandLine(int argc, char** argv)
       { "delta",        'r', 1, 'd', &cmd.initialDelta,   0, "initial delta (Angstroms)" },
       { "hilbert",      'H', 0, 'i', &cmd.doHilbert,      0, "space-filling curve for the traversal of cells (not supported)" },
       { "skinDistance", 'S', 1, 'd', &cmd.relativeSkinDistance, 0, "skinDistance (relative to cutoff (default: 0.1))" },
-      { "method",       'm', 1, 's', cmd.method,  sizeof cmd.method,  "thread_atom,cta_cell (warp_atom and *_nl map to thread_atom)" },
+      { "method",       'm', 1, 's', cmd.method,  sizeof cmd.method,  "thread_atom,thread_atom_nl,cta_cell (warp_atom[_nl] run as thread_atom[_nl])" },
       { "gpuAsync",     'a', 1, 'i', &cmd.gpuAsync,       0, "communicaton hiding optimization using streams" },
       { "gpuProfile",   's', 0, 'i', &cmd.gpuProfile,     0, "profiling mode: reboxing disabled, single kernel run" },
       { "ljInterpolation", 'I', 0, 'i', &cmd.ljInterpolation, 0, "Lennard-Jones by table interpolation (not supported)" },
       { "spline",       'P', 0, 'i', &cmd.spline,         0, "spline interpolation (not supported)" },
       { "usePairlist",  'L', 0, 'i', &cmd.usePairlist,    0, "pairlists for cta_cell LJ (not supported)" },
       { "maxAtoms",      0,  1, 'i', &cmd.maxAtoms,       0, "link-cell slot capacity (0 = from the lattice)" },
+      { "maxNeighbors",  0,  1, 'i', &cmd.maxNeighbors,   0, "neighbour-list rows per atom for *_nl (0 = from cutoff + skin)" },
       { "quiet",         0,  0, 'i', &cmd.quiet,          0, "no stdout report" },
    };
    const int nDefs = (int)(sizeof defs / sizeof defs[0]);

@@ -31,7 +31,7 @@ typedef struct CommandSt {
    char potDir[1024], potName[1024], potType[1024], method[1024];
    int doeam, nx, ny, nz, xproc, yproc, zproc, nSteps, printRate;
    double dt, lat, temperature, initialDelta, relativeSkinDistance;
-   int doHilbert, gpuAsync, gpuProfile, ljInterpolation, spline, usePairlist;
+   int doHilbert, gpuAsync, gpuProfile, ljInterpolation, spline, usePairlist, maxNeighbors;
    int maxAtoms;          /* extension: link-cell slot capacity, 0 = choose from the lattice (reference: -DMAXATOMS) */
    int quiet;             /* extension: suppress the stdout report (library use) */
 } Command;
@@ -179,10 +179,16 @@ typedef struct ForceExchangeParmsSt {
    int *sendOffsetsGpu[6], *recvOffsetsGpu[6];   /* device, nCells + 1 each: filled by one batched scan per step */
    int* d_cellOffsets;
    int capacityAtoms;
+   int positions;                         /* 0: dF/drho (1 real per atom); 1: positions + face shift (3 reals per atom) */
+   real_t shift[6][3];
+   int msgBytesCached[6];                 /* positions: message sizes are fixed between list builds; -1 = unknown */
 } ForceExchangeParms;
 
 HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice);
 HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice);
+/* Verlet-list mode: refresh of the halo copies' positions between list builds, over the force exchange's cell lists */
+HaloExchange* initPositionHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice);
+void preparePositionExchange(HaloExchange* positionExchange, struct SimFlatSt* sim);   /* after every list build */
 void destroyHaloExchange(HaloExchange** haloExchange);
 void haloExchange(HaloExchange* haloExchange, void* data);
 void exchangeData(HaloExchange* haloExchange, void* data, int iAxis);
@@ -202,6 +208,7 @@ typedef struct SimFlatSt {
    real_t ePotential, eKinetic;
    BasePotential* pot;
    HaloExchange* atomExchange;
+   HaloExchange* positionExchange;  /* *_nl methods only */
    SimGpu gpu;
    int method;
    int n_boundary_cells, n_boundary1_cells;
@@ -209,6 +216,9 @@ typedef struct SimFlatSt {
    int gpuAsync, gpuProfile;
    int ljInterpolation, spline, usePairlist;
    real_t skinDistance;
+   int useNL;                       /* method is thread_atom_nl / warp_atom_nl */
+   int interiorLaunched;            /* -a 1: redistributeAtoms has already started the interior cells' force work */
+   int nlBuilds;                    /* list builds so far (reported) */
    int quiet, cmdDoeam;
    int iStepPrev, firstPrint;       /* printThings state (static locals in CoMD.c:466-467) */
 } SimFlat;
@@ -228,6 +238,7 @@ double timestep(SimFlat* s, int n, real_t dt);
 void computeForce(SimFlat* s);
 void kineticEnergyGpu(SimFlat* s);
 void redistributeAtoms(SimFlat* sim);
+void ensureInteriorForceLaunched(SimFlat* sim);
 
 /* ---- performanceTimers.h ---- */
 enum TimerHandle { totalTimer, loopTimer, timestepTimer, positionTimer, velocityTimer, redistributeTimer, atomHaloTimer,
@@ -259,6 +270,7 @@ void     comdNeighborRanks(SimFlat* s, int nbr[6], int coord[3]);
 void     comdHaloExchangeHost(SimFlat* s, int (*load)(void*, void*, int, char*), void (*unload)(void*, void*, int, int, char*));
 void     comdFaceShift(SimFlat* s, int face, double out[3]);
 int      comdPutAtomInBox(SimFlat* s, int gid, int type, const double r[3], const double p[3]);
+int      comdNeighborListBuilds(SimFlat* s);              /* Verlet-list builds so far (*_nl methods) */
 void     comdGridInfo(SimFlat* s, int out[6]);            /* gridSize[3], nLocalBoxes, nTotalBoxes, maxAtoms */
 int      comdMain(int argc, char** argv);                /* the reference's main(): CoMD.c:86-187 */
 void     comdDestroy(SimFlat* s);

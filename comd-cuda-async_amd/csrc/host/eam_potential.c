@@ -177,6 +177,7 @@ static int eamForce(SimFlat* s)
    SimGpu* g = &s->gpu;
    if (s->gpuAsync) {
       /* passes 1-2 of the interior cells were launched on interior_stream by redistributeAtoms (timestep.c:257-265) */
+      ensureInteriorForceLaunched(s);
       eamForce1GpuAsync(g, s->n_boundary_cells, g->boundary_cells, s->method, g->boundary_stream, s->spline);
       eamForce2GpuAsync(g, s->n_boundary_cells, g->boundary_cells, s->method, g->boundary_stream, s->spline);
       comdStreamSynchronize(g->boundary_stream);       /* boundary dfEmbed must exist before it is packed */

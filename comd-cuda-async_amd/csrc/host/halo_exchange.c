@@ -225,6 +225,93 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
    return hh;
 }
 
+/* ---- position refresh plugin (Verlet-list mode) ----------------------------------------------------------------
+ * Between list builds nothing is re-binned, so the halo cells of a rank hold the same atoms, in the same slots, as the send
+ * cells of its neighbour did at the build: the exchange is positional, exactly like dF/drho, with three reals per atom and
+ * the periodic shift of the face added on the way out.  Cell lists, growing x -> y -> z footprint and buffers are those of
+ * initForceHaloExchange.  (The reference re-sends whole atoms and looks their slots up in a gid hash table,
+ * haloExchange.c:1622-1700.)  Message sizes cannot change between builds: read once, then cached. */
+static int loadPositionBuffer(void* vparms, void* vdata, int face, char* buf)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
+   loadPositionBufferFromGpu((real_t*)buf, parms->nCells[face], parms->sendCellsGpu[face], parms->sendOffsetsGpu[face], parms->shift[face],
+                             &s->gpu, s->gpu.boundary_stream);
+   return parms->msgBytesCached[face];
+}
+
+static int positionMsgBytes(void* vparms, void* vdata, int face, char* buf)
+{
+   (void)buf;
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
+   if (parms->msgBytesCached[face] < 0) {
+      int n = comdReadDeviceInt(parms->sendOffsetsGpu[face] + parms->nCells[face], s->gpu.boundary_stream);
+      parms->msgBytesCached[face] = 3 * n * (int)sizeof(real_t);
+   }
+   return parms->msgBytesCached[face];
+}
+
+static void unloadPositionBuffer(void* vparms, void* vdata, int face, int bufSize, char* buf)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
+   (void)bufSize;
+   unloadPositionBufferToGpu((const real_t*)buf, parms->nCells[face], parms->recvCellsGpu[face], parms->recvOffsetsGpu[face], &s->gpu, s->gpu.boundary_stream);
+}
+
+HaloExchange* initPositionHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice)
+{
+   /* same cell lists and offsets as the force exchange; 3x the payload */
+   HaloExchange* hh = initHaloExchangeBase(domain);
+   const int* g = boxes->gridSize;
+   const int size0 = g[1] * g[2], size1 = (g[0] + 2) * g[2], size2 = (g[0] + 2) * (g[1] + 2);
+   const int maxSize = MAXI(size0, MAXI(size1, size2));
+   ForceExchangeParms* parms = (ForceExchangeParms*)calloc(1, sizeof(ForceExchangeParms));
+   parms->positions = 1;
+   parms->capacityAtoms = maxSize * boxes->maxAtoms;
+   hh->bufCapacity = 3 * parms->capacityAtoms * (int)sizeof(real_t);
+   hh->loadBuffer = loadPositionBuffer;
+   hh->msgBytes = positionMsgBytes;
+   hh->unloadBuffer = unloadPositionBuffer;
+   hh->destroy = destroyForceExchange;
+   parms->nCells[HALO_X_MINUS] = parms->nCells[HALO_X_PLUS] = size0;
+   parms->nCells[HALO_Y_MINUS] = parms->nCells[HALO_Y_PLUS] = size1;
+   parms->nCells[HALO_Z_MINUS] = parms->nCells[HALO_Z_PLUS] = size2;
+   for (int f = 0; f < 6; ++f) {
+      parms->sendCells[f] = mkForceSendCellList(boxes, f, parms->nCells[f]);
+      parms->recvCells[f] = mkForceRecvCellList(boxes, f, parms->nCells[f]);
+      parms->msgBytesCached[f] = -1;
+   }
+   for (int a = 0; a < 3; ++a) {               /* haloExchange.c:316-323 */
+      if (domain->procCoord[a] == 0)                       parms->shift[2*a][a]     = +1.0 * domain->globalExtent[a];
+      if (domain->procCoord[a] == domain->procGrid[a] - 1) parms->shift[2*a + 1][a] = -1.0 * domain->globalExtent[a];
+   }
+   hh->type = 2;
+   hh->parms = parms;
+   hh->deviceBuffers = allocDevice;
+   if (allocDevice) {
+      for (int f = 0; f < 6; ++f) {
+         parms->sendCellsGpu[f] = uploadInts(parms->sendCells[f], parms->nCells[f]);
+         parms->recvCellsGpu[f] = uploadInts(parms->recvCells[f], parms->nCells[f]);
+         parms->sendOffsetsGpu[f] = (int*)comdDeviceMalloc((long)(parms->nCells[f] + 1) * sizeof(int));
+         parms->recvOffsetsGpu[f] = (int*)comdDeviceMalloc((long)(parms->nCells[f] + 1) * sizeof(int));
+      }
+      parms->d_cellOffsets = (int*)comdDeviceMalloc((long)(maxSize + 1) * sizeof(int));
+      hh->sendBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->sendBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
+      hh->recvBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->recvBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
+   }
+   return hh;
+}
+
+/* after a list build: occupancies are frozen until the next one -- scan the twelve cell lists once, forget the cached sizes */
+void preparePositionExchange(HaloExchange* hh, SimFlat* sim)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)hh->parms;
+   prepareForceExchange(hh, sim);
+   for (int f = 0; f < 6; ++f) parms->msgBytesCached[f] = -1;
+}
+
 void destroyHaloExchange(HaloExchange** pp)
 {
    if (!pp || !*pp) return;

@@ -52,6 +52,7 @@ static int ljForce(SimFlat* sim)
 {
    if (sim->gpuAsync) {
       /* interior cells were launched on interior_stream before the halo exchange */
+      ensureInteriorForceLaunched(sim);
       ljForceGpuAsync(&sim->gpu, sim->n_boundary_cells, sim->gpu.boundary_cells, sim->method, sim->gpu.boundary_stream);
       comdStreamSynchronize(sim->gpu.interior_stream);
       comdStreamSynchronize(sim->gpu.boundary_stream);

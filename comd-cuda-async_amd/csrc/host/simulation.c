@@ -100,11 +100,17 @@ SimFlat* initSimulationHost(Command cmd)
 
    if (!strcmp(cmd.method, "thread_atom")) sim->method = THREAD_ATOM;
    else if (!strcmp(cmd.method, "cta_cell")) sim->method = CTA_CELL;
-   else if (!strcmp(cmd.method, "warp_atom") || !strcmp(cmd.method, "warp_atom_nl") || !strcmp(cmd.method, "thread_atom_nl")) {
-      if (printRank()) printf("Method %s is outside this build's scope; using thread_atom.\n", cmd.method);
+   else if (!strcmp(cmd.method, "thread_atom_nl")) sim->method = THREAD_ATOM_NL;
+   else if (!strcmp(cmd.method, "warp_atom_nl")) {
+      if (printRank()) printf("Method warp_atom_nl runs as thread_atom_nl in this build.\n");
+      sim->method = THREAD_ATOM_NL;
+   }
+   else if (!strcmp(cmd.method, "warp_atom")) {
+      if (printRank()) printf("Method warp_atom runs as thread_atom in this build.\n");
       sim->method = THREAD_ATOM;
    }
-   else { printf("Error: You have to specify a valid method: -m [thread_atom,cta_cell]\n"); exit(-1); }
+   else { printf("Error: You have to specify a valid method: -m [thread_atom,thread_atom_nl,cta_cell]\n"); exit(-1); }
+   sim->useNL = sim->method == THREAD_ATOM_NL;
    if (cmd.ljInterpolation || cmd.spline || cmd.usePairlist || cmd.doHilbert) {
       printf("Error: -I, -P, -L and -H are outside this build's scope (SURVEY.md section 8f).\n"); exit(-1);
    }
@@ -117,7 +123,10 @@ SimFlat* initSimulationHost(Command cmd)
 
    const real_t globalExtent[3] = { cmd.nx * latticeConstant, cmd.ny * latticeConstant, cmd.nz * latticeConstant };
    sim->domain = initDecomposition(cmd.xproc, cmd.yproc, cmd.zproc, globalExtent);
-   sim->skinDistance = 0.0;                        /* no Verlet lists in this build (CoMD.c:257-268) */
+   /* CoMD.c:257-268: the *_nl methods list neighbours out to cutoff + skin and size the link cells to match */
+   sim->skinDistance = sim->useNL ? sim->pot->cutoff * cmd.relativeSkinDistance : 0.0;
+   if (sim->useNL && printRank() && !cmd.quiet) printf("Skin-Distance: %f\n", sim->skinDistance);
+   if (sim->useNL && sim->skinDistance <= 0.0) { printf("Error: the *_nl methods need a positive skin distance (-S)\n"); exit(-1); }
    sim->boxes = initLinkCells(sim->domain, sim->pot->cutoff + sim->skinDistance);
 
    int cap = cmd.maxAtoms;
@@ -166,11 +175,14 @@ SimFlat* initSimulation(Command cmd)
       for (int j = 0; j < 27; ++j) if (nbr[j] != iBox) nbrTable[iBox * 27 + c++] = nbr[j];
    }
    cfg.neighborCells = nbrTable;
+   cfg.skinDistance = sim->skinDistance; cfg.maxNeighbors = cmd.maxNeighbors;
+   cfg.latticeConstant = cmd.lat < 0.0 ? sim->pot->lat : cmd.lat;
    AllocateGpu(&sim->gpu, &cfg);
    free(nbrTable);
 
    sim->atomExchange = initAtomHaloExchange(sim->domain, sim->boxes, 1);
    if (cmd.doeam) ((EamPotential*)sim->pot)->forceExchange = initForceHaloExchange(sim->domain, sim->boxes, 1);
+   if (sim->useNL) sim->positionExchange = initPositionHaloExchange(sim->domain, sim->boxes, 1);
    setBoundaryCellsHost(sim, sim->atomExchange);
    CopyDataToGpu(&sim->gpu, &sim->atoms->h);
 
@@ -192,6 +204,7 @@ void destroySimulation(SimFlat** ps)
    if (!ps || !*ps) return;
    SimFlat* s = *ps;
    if (s->atomExchange) destroyHaloExchange(&s->atomExchange);
+   if (s->positionExchange) destroyHaloExchange(&s->positionExchange);
    BasePotential* pot = s->pot;
    if (pot) pot->destroy(&pot);
    if (s->gpu.boxes.nAtoms) DestroyGpu(&s->gpu);
@@ -366,6 +379,8 @@ SimFlat* comdCreateHostOnly(int argc, char** argv)
 }
 
 const HostAtoms* comdHostAtoms(SimFlat* s) { return &s->atoms->h; }
+
+int comdNeighborListBuilds(SimFlat* s) { return s->nlBuilds; }
 
 void comdGridInfo(SimFlat* s, int out[6])
 {

@@ -51,22 +51,74 @@ void kineticEnergyGpu(SimFlat* s)
    s->eKinetic = eSum[1];
 }
 
-/* timestep.c:222-276 redistributeAtomsGpu */
+static void launchInteriorForce(SimFlat* sim)
+{
+   SimGpu* g = &sim->gpu;
+   if (sim->gpu.do_eam) {
+      eamForce1GpuAsync(g, g->n_interior_cells, g->interior_cells, sim->method, g->interior_stream, sim->spline);
+      eamForce2GpuAsync(g, g->n_interior_cells, g->interior_cells, sim->method, g->interior_stream, sim->spline);
+   } else {
+      ljForceGpuAsync(g, g->n_interior_cells, g->interior_cells, sim->method, g->interior_stream);
+   }
+   sim->interiorLaunched = 1;
+}
+
+/* -a 1: the potentials call this before their boundary work; starts the interior cells if redistributeAtoms could not
+ * (a Verlet-list build had to come first) */
+void ensureInteriorForceLaunched(SimFlat* sim)
+{
+   if (sim->gpuAsync && !sim->interiorLaunched) {
+      comdStreamSynchronize(sim->gpu.boundary_stream);
+      launchInteriorForce(sim);
+   }
+}
+
+static void redistributeAtomsCells(SimFlat* sim, int overlapInterior);
+
+/* timestep.c:278-352 redistributeAtomsGpuNL.  Lists valid (no atom has moved more than skin/2 since the build, on any rank):
+ * nothing is re-binned, atoms keep their slots, only the halo copies' positions are refreshed.  Otherwise: the ordinary
+ * redistribution (re-bin, migrate, full atom exchange, gid sort) followed by a list build.  The reference also rebuilds on every
+ * rank whenever an atom changed owner (:331-350); here owners only change inside the ordinary redistribution. */
+static void redistributeAtomsNL(SimFlat* sim)
+{
+   SimGpu* g = &sim->gpu;
+   int need = neighborListUpdateRequiredGpu(g), needAll = 0;
+   startTimer(commReduceTimer);
+   maxIntParallel(&need, &needAll, 1);
+   stopTimer(commReduceTimer);
+   sim->interiorLaunched = 0;
+   if (needAll) {
+      redistributeAtomsCells(sim, 0);
+      startTimer(neighborListBuildTimer);
+      buildNeighborListGpu(g, sim->method, 0);
+      preparePositionExchange(sim->positionExchange, sim);
+      stopTimer(neighborListBuildTimer);
+      sim->nlBuilds++;
+   } else {
+      if (sim->gpuAsync) { comdStreamSynchronize(g->boundary_stream); launchInteriorForce(sim); }
+      startTimer(atomHaloTimer);
+      haloExchange(sim->positionExchange, sim);
+      stopTimer(atomHaloTimer);
+   }
+}
+
 void redistributeAtoms(SimFlat* sim)
+{
+   if (sim->useNL) redistributeAtomsNL(sim);
+   else { sim->interiorLaunched = 0; redistributeAtomsCells(sim, 1); }
+}
+
+/* timestep.c:222-276 redistributeAtomsGpu */
+static void redistributeAtomsCells(SimFlat* sim, int overlapInterior)
 {
    SimGpu* g = &sim->gpu;
    /* empties the halo cells, moves atoms that left their cell, compacts + gid-sorts the cells that changed */
    updateLinkCellsGpu(g, g->boundary_stream);
 
-   if (sim->gpuAsync) {
+   if (sim->gpuAsync && overlapInterior) {
       /* local cells are final: start the interior force work while the halo exchange runs (timestep.c:257-265) */
       comdStreamSynchronize(g->boundary_stream);
-      if (sim->gpu.do_eam) {
-         eamForce1GpuAsync(g, g->n_interior_cells, g->interior_cells, sim->method, g->interior_stream, sim->spline);
-         eamForce2GpuAsync(g, g->n_interior_cells, g->interior_cells, sim->method, g->interior_stream, sim->spline);
-      } else {
-         ljForceGpuAsync(g, g->n_interior_cells, g->interior_cells, sim->method, g->interior_stream);
-      }
+      launchInteriorForce(sim);
    }
 
    startTimer(atomHaloTimer);

@@ -61,12 +61,27 @@ typedef struct LinkCellGpu {
    int*   nAtoms;                      /* device [nTotalBoxes] */
 } LinkCellGpu;
 
+/* gpu_types.h:120-146 NeighborListGpu.  Verlet lists for the *_nl methods: every atom within cutoff + skinDistance of a local
+ * atom, valid until some atom has moved more than skinDistance/2 since the build.  An entry is the neighbour's global slot:
+ * between builds no atom changes slot (nothing is re-binned, halo copies are refreshed in place). */
+typedef struct NeighborListGpu {
+   int*   list;                        /* device [nLocalBoxes * maxNeighbors * maxAtoms]: entry k of atom i of cell c at (c*maxNeighbors + k)*maxAtoms + i */
+   int*   nNeighbors;                  /* device [nLocalBoxes * maxAtoms] */
+   int    maxNeighbors;                /* rows per cell (gpu_neighborList.c:50 MAXNEIGHBORLISTSIZE) */
+   vec_t  lastR;                       /* device [nLocalBoxes * maxAtoms]: positions at the last build */
+   int*   updateRequired;              /* device [1] */
+   real_t skinDistance, skinDistance2, skinDistanceHalf2;
+   int    forceRebuildFlag;            /* host: the next neighborListUpdateRequiredGpu answers 1 without looking */
+   int    nBuilds;                     /* host: builds since AllocateGpu */
+} NeighborListGpu;
+
 /* gpu_types.h:148-157 */
 typedef struct AtomsGpu {
    vec_t   r, p, f;                    /* device SoA, [nTotalBoxes*maxAtoms] each */
    real_t* e;
    int*    iSpecies;
    int*    gid;                        /* -1 marks a hole between updateLinkCellsGpu's two phases */
+   NeighborListGpu neighborList;       /* allocated only when GpuConfig.skinDistance > 0 */
 } AtomsGpu;
 
 /* gpu_types.h:159-190.  Passed by pointer everywhere (the reference passes 856 bytes by value). */
@@ -111,6 +126,9 @@ typedef struct GpuConfig {
    real_t phiX0, phiInvDx, rhoX0, rhoInvDx, fX0, fInvDx;
    const real_t *phiValues, *rhoValues, *fValues; /* host, n+3 entries each, element 0 = values[-1] */
    const int* neighborCells;                      /* host [nLocalBoxes*27] */
+   real_t skinDistance;                           /* > 0: allocate Verlet lists (AllocateGpu's third argument, gpu_utility.c:165) */
+   int    maxNeighbors;                           /* list rows per atom; 0 = derive from cutoff + skin and the FCC density */
+   real_t latticeConstant;                        /* for that estimate */
 } GpuConfig;
 
 /* Host-side mirror of the slot arrays (CoMDTypes.h Atoms / gpu_utility.c:432-600 staging). */
@@ -157,7 +175,8 @@ void comdCheckStatus(SimGpu* sim, const char* where);
 /* ---- force: gpu_kernels.h:13-24 ------------------------------------------------------------ */
 /* ljForceGpu(SimGpu*, interpolation, num_cells, cells_list, plcutoff, method), gpu_kernels.cu:69-122.
  * cells_list (device) == NULL means cells 0..num_cells-1.  interpolation/plcutoff are accepted for
- * signature parity and must be 0 (table-LJ and pairlists are out of scope): non-zero exits. */
+ * signature parity: interpolation must be 0 (table-LJ is out of scope; non-zero exits), plcutoff is ignored (pairlists likewise).
+ * method THREAD_ATOM_NL / WARP_ATOM_NL walks the Verlet lists (buildNeighborListGpu must have run). */
 void ljForceGpu(SimGpu* sim, int interpolation, int num_cells, int* cells_list, real_t plcutoff, int method);
 void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream);
 /* The per-atom energy array e[] is read only by computeEnergy.  comdSetEnergyNeeded(0) tells the force wrappers that the
@@ -267,13 +286,26 @@ int  comdCommInitRank(const char* id128, int rank, int nRanks, CommTransport* ou
 int  comdCommInitFromEnv(CommTransport* out, int* rank, int* nRanks, int* localRank);
 void comdCommFinalize(void);
 
-/* ---- neighbour-list / pairlist bookkeeping: gpu_kernels.h:25, 73-78, 87-92 ------------------
- * Out of the hot-path scope.  Exported so the reference's host objects link;
- * "always rebuild" semantics, no state. */
+/* ---- Verlet neighbour lists (methods thread_atom_nl / warp_atom_nl): gpu_kernels.h:25, 73-78, 87-92 ------------------
+ * The reference offers them for EAM only (CoMD.c:291-295 exits for LJ); here both potentials take them. */
+/* emptyNeighborListGpu(SimGpu*, boundaryFlag), gpu_kernels.cu:1063-1085: zero the neighbour counts */
 void emptyNeighborListGpu(SimGpu* sim, int boundaryFlag);
+/* neighborListUpdateRequiredGpu(SimGpu*), gpu_kernels.cu:1449-1484: 1 when forceRebuildFlag is set or some local atom has moved
+ * more than skin/2 since the build (blocking read of one flag).  THIS rank's answer; the caller reduces over ranks. */
 int  neighborListUpdateRequiredGpu(SimGpu* sim);
-int  pairlistUpdateRequiredGpu(SimGpu* sim);
+/* neighborListForceRebuildGpu(NeighborListGpu*), gpu_neighborList.c:88-93 */
+void neighborListForceRebuildGpu(SimGpu* sim);
+/* buildNeighborListGpu(SimGpu*, method, boundaryFlag), gpu_kernels.cu:1975-2029: list every atom within cutoff + skin of each
+ * local atom (cells must be current: call after the atom exchange), snapshot lastR, clear forceRebuildFlag.
+ * boundaryFlag is accepted for signature parity (BOTH = 0 is the only mode the reference enables, timestep.c:59-82). */
 void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag);
+/* pairlists (-L) stay out of scope: always "rebuild" */
+int  pairlistUpdateRequiredGpu(SimGpu* sim);
+/* Between list builds the halo copies keep their slots and only their positions are refreshed: gather r (+ the periodic shift of
+ * the face) of the listed cells, in list order, into gpu_buf (3 real_t per atom); scatter them into the receive cells.  The
+ * reference re-sends whole atoms and finds their slots through a gid hash table (haloExchange.c:1622-1700, hashTable.c). */
+void loadPositionBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, const real_t shift[3], SimGpu* sim, comdStream_t stream);
+void unloadPositionBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream);
 
 /* ---- device-side timing for bench.py -------------------------------------------------------- */
 /* HIP-event pair on a stream: comdEventCreate/Record/ElapsedMs.  Used to time kernels on the stream they

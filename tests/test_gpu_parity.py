@@ -114,6 +114,39 @@ def test_eam_cohesive_energy(gpu):
         assert abs(_per_atom(sim)[1] - G["repo_native"]["eam_adams_cohesive_energy"]["value"]) < TOL["energy_per_atom_step0"]
 
 
+# ---------------------------------------------------------------- Verlet neighbour lists (-m thread_atom_nl)
+@pytest.mark.parametrize("eam,n,delta", [(0, 12, 0.0), (0, (11, 13, 12), 0.2), (1, 8, 0.1), (1, (7, 9, 12), 0.3)])
+def test_neighbor_list_forces_match_oracle(gpu, orc, eam, n, delta):
+    """Lists hold everything within cutoff + skin; the force pass keeps r <= cutoff only, so forces do not depend on the skin."""
+    with gpu.Simulation(_args(n, eam, delta, "thread_atom_nl")) as sim:
+        o = orc.Oracle(n, eam=eam, delta=delta)
+        fo, eo = o.gather(orc.F), o.gather(orc.U)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
+        assert np.abs(sim.gather(3) - eo).max() <= TOL["per_atom_energy_abs"]
+        (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
+        assert abs(ep - op) / ng < TOL["energy_per_atom_step0"]
+        assert sim.nl_builds == 1
+
+
+@pytest.mark.parametrize("key,skin", [("lj_20", 0.1), ("eam_20", 0.1), ("eam_20", 0.02), ("eam_20", 0.3)])
+def test_neighbor_list_trace_matches_reference(gpu, key, skin):
+    """100 steps with lists reused between builds reproduce the reference's energy trace (its own CPU runs with skins
+    0.02 / 0.1 / 0.3 agree to 12 digits); the lists must be rebuilt now and then, not every step."""
+    ref = S[key]
+    with gpu.Simulation(_args(ref["nx"], ref["eam"], 0.0, "thread_atom_nl", ["-S", skin])) as sim:
+        done = 0
+        for step in (10, 50, 100):
+            sim.step(step - done)
+            done = step
+            assert abs(_per_atom(sim)[0] - ref["E_at"][str(step)]) < TOL["energy_per_atom_trace"], step
+        # LJ: skin/2 = 0.58 A is more than an atom travels in 100 fs -> the first list lasts; EAM skin 0.02: 0.05 A -> frequent rebuilds
+        assert 1 <= sim.nl_builds < (102 if skin < 0.05 else 40), sim.nl_builds
+        if skin < 0.05:
+            assert sim.nl_builds > 5
+        sim.sum_atoms()
+        assert sim.energy()[2] == 4 * ref["nx"] ** 3
+
+
 SETFL = ["-t", "setfl", "-p", "Cu01.eam.alloy"]
 
 

@@ -50,14 +50,15 @@ def test_host_logic_two_processes_gloo(grid, eam, n):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("grid,eam,n,method,use_async", [((2, 1, 1), 1, 10, "cta_cell", 0), ((2, 2, 1), 1, 12, "thread_atom", 1),
-                                                           ((1, 2, 1), 0, 14, "thread_atom", 0), ((2, 1, 2), 0, 20, "cta_cell", 1)])
+                                                           ((1, 2, 1), 0, 14, "thread_atom", 0), ((2, 1, 2), 0, 20, "cta_cell", 1),
+                                                           ((2, 1, 1), 1, 12, "thread_atom_nl", 0), ((1, 2, 1), 0, 22, "thread_atom_nl", 1)])
 def test_gpu_path_multi_rank_shared_device(grid, eam, n, method, use_async):
     outs = _launch("gpu", grid, eam, n, extra=(method, use_async))
     assert "gpu-mode OK" in outs[0]
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("eam,n,method,use_async", [(0, 14, "thread_atom", 0), (1, 10, "cta_cell", 1)])
+@pytest.mark.parametrize("eam,n,method,use_async", [(0, 14, "thread_atom", 0), (1, 10, "cta_cell", 1), (1, 10, "thread_atom_nl", 1)])
 def test_rccl_transport_loopback(eam, n, method, use_async):
     """comm_rccl.hip on real hardware: a one-rank RCCL communicator carries all six halo messages per exchange (size handshake +
     grouped ncclSend/ncclRecv to itself), the EAM dF/drho exchange and the energy / atom-count reductions."""
