@@ -43,7 +43,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pot", choices=["lj", "eam"], default="lj")
-    ap.add_argument("--method", choices=["thread_atom", "cta_cell"], default=None)
+    ap.add_argument("--method", choices=["thread_atom", "thread_atom_nl", "cta_cell"], default=None)
     ap.add_argument("--nx", type=int, default=80, help="unit cells per GPU along each axis")
     ap.add_argument("--async-halo", type=int, default=None, help="-a flag: overlap interior force with the halo exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -186,8 +186,23 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
       }
       if (nl->maxNeighbors > 27 * cfg->maxAtoms) nl->maxNeighbors = 27 * cfg->maxAtoms;
       const size_t localSlots = (size_t)cfg->nLocalBoxes * cfg->maxAtoms;
-      nl->list = dalloc<int>(localSlots * nl->maxNeighbors, false);
-      nl->nNeighbors = dalloc<int>(localSlots);
+      nl->slabFormat = !cfg->do_eam && cfg->maxAtoms % 64 == 0 && cfg->maxAtoms <= 512 && !getenv("COMD_NL_GLOBAL");
+      if (nl->slabFormat) {
+         // share of the list sphere (radius R) one group can hold.  3 groups: the atom's own x-plane of cells, thickness wx, cuts at
+         // most wx * pi R^2 out of 4/3 pi R^3 (78 % for cells of about R); 9 groups: its own z-column, wx * wy * 2R (51 %)
+         const double R = cutoff + cfg->skinDistance;
+         double share = NL_GROUPS == 3 ? 3.0 * cfg->boxSize[0] / (4.0 * R)
+                                       : 3.0 * cfg->boxSize[0] * cfg->boxSize[1] / (2.0 * 3.14159265358979 * R * R);
+         if (share > 1.0) share = 1.0;
+         nl->slabRows = ((int)(share * nl->maxNeighbors) + 7) / 8 * 8;
+         if (nl->slabRows > NL_GROUP_CELLS * cfg->maxAtoms) nl->slabRows = NL_GROUP_CELLS * cfg->maxAtoms;
+         nl->list16 = dalloc<unsigned short>(localSlots * NL_GROUPS * nl->slabRows, false);
+         nl->nNeighbors = dalloc<int>(localSlots * NL_GROUPS);
+         nl->stats = dalloc<int>(2);
+      } else {
+         nl->list = dalloc<int>(localSlots * nl->maxNeighbors, false);
+         nl->nNeighbors = dalloc<int>(localSlots);
+      }
       nl->lastR.x = dalloc<real_t>(localSlots); nl->lastR.y = dalloc<real_t>(localSlots); nl->lastR.z = dalloc<real_t>(localSlots);
       nl->updateRequired = dalloc<int>(1);
       nl->forceRebuildFlag = 1; nl->nBuilds = 0;
@@ -270,7 +285,8 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->eam_pot.rhobar, sim->eam_pot.dfEmbed, sim->nAtomsPrev, sim->cellDirty, sim->status, sim->reduceBuf,
                     sim->boundary_cells, sim->interior_cells, sim->boundary1_cells,
                     sim->atoms.neighborList.list, sim->atoms.neighborList.nNeighbors, sim->atoms.neighborList.lastR.x,
-                    sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired };
+                    sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
+                    sim->atoms.neighborList.list16, sim->atoms.neighborList.stats };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
@@ -314,7 +330,7 @@ extern "C" int comdReadDeviceInt(const int* d_ptr, comdStream_t stream)
 static NlView nlView(SimGpu* sim)
 {
    NeighborListGpu* n = &sim->atoms.neighborList;
-   if (!n->list) { fprintf(stderr, "the *_nl methods need Verlet lists: allocate with GpuConfig.skinDistance > 0\n"); exit(-1); }
+   if (!n->list && !n->list16) { fprintf(stderr, "the *_nl methods need Verlet lists: allocate with GpuConfig.skinDistance > 0\n"); exit(-1); }
    if (n->nBuilds == 0) { fprintf(stderr, "the *_nl methods need buildNeighborListGpu before the first force call\n"); exit(-1); }
    NlView v; v.list = n->list; v.count = n->nNeighbors; v.maxNbr = n->maxNeighbors;
    return v;
@@ -346,7 +362,21 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
    if (num_cells <= 0) return;
    LjArgs a = makeLjArgs(sim, num_cells, cells_list);
    ForceTimer timer(S(stream));
-   if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
+   if ((method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat) {
+      NeighborListGpu* n = &sim->atoms.neighborList;
+      (void)nlView(sim);
+      NlSlabView v; v.list = n->list16; v.count = n->nNeighbors; v.rows = n->slabRows;
+      const int threads = ((n->maxCellAtoms + 63) / 64) * 64;
+      const size_t lds = (size_t)3 * n->maxSlabAtoms * sizeof(double);
+      static size_t attrSet = 0;
+      if (lds > attrSet) {
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_nl_slabs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_nl_slabs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         attrSet = lds;
+      }
+      if (g_needEnergy) hipLaunchKernelGGL(LJ_Force_nl_slabs<true>, dim3(num_cells), dim3(threads), lds, S(stream), a, v, n->maxSlabAtoms);
+      else              hipLaunchKernelGGL(LJ_Force_nl_slabs<false>, dim3(num_cells), dim3(threads), lds, S(stream), a, v, n->maxSlabAtoms);
+   } else if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
       const NlView nl = nlView(sim);
       const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
       if (g_needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom_nl<true>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
@@ -619,7 +649,7 @@ extern "C" void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d
 extern "C" void emptyNeighborListGpu(SimGpu* sim, int)
 {
    NeighborListGpu* n = &sim->atoms.neighborList;
-   if (n->nNeighbors) HIP_CHECK(hipMemsetAsync(n->nNeighbors, 0, (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * sizeof(int), S(sim->boundary_stream)));
+   if (n->nNeighbors) HIP_CHECK(hipMemsetAsync(n->nNeighbors, 0, (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * (n->slabFormat ? NL_GROUPS : 1) * sizeof(int), S(sim->boundary_stream)));
 }
 
 extern "C" void neighborListForceRebuildGpu(SimGpu* sim) { sim->atoms.neighborList.forceRebuildFlag = 1; }
@@ -627,7 +657,7 @@ extern "C" void neighborListForceRebuildGpu(SimGpu* sim) { sim->atoms.neighborLi
 extern "C" int neighborListUpdateRequiredGpu(SimGpu* sim)
 {
    NeighborListGpu* n = &sim->atoms.neighborList;
-   if (!n->list || n->forceRebuildFlag) return 1;
+   if ((!n->list && !n->list16) || n->forceRebuildFlag) return 1;
    hipStream_t st = S(sim->boundary_stream);
    HIP_CHECK(hipMemsetAsync(n->updateRequired, 0, sizeof(int), st));
    hipLaunchKernelGGL(NeighborListUpdateRequired, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
@@ -641,9 +671,26 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
 {
    (void)method; (void)boundaryFlag;
    NeighborListGpu* n = &sim->atoms.neighborList;
-   if (!n->list) { fprintf(stderr, "buildNeighborListGpu: no lists allocated (GpuConfig.skinDistance == 0)\n"); exit(-1); }
+   if (!n->list && !n->list16) { fprintf(stderr, "buildNeighborListGpu: no lists allocated (GpuConfig.skinDistance == 0)\n"); exit(-1); }
    const real_t cutoff = sim->do_eam ? sim->eam_pot.cutoff : sim->lj_pot.cutoff;
    const real_t rBuild = cutoff + n->skinDistance;
+   if (n->slabFormat) {
+      hipStream_t st = S(sim->boundary_stream);
+      NlSlabView sv; sv.list = n->list16; sv.count = n->nNeighbors; sv.rows = n->slabRows;
+      HIP_CHECK(hipMemsetAsync(n->stats, 0, 2 * sizeof(int), st));
+      hipLaunchKernelGGL(BuildNeighborListSlabs, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
+                         sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
+                         sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);
+      LAUNCH_CHECK();
+      int h[2];
+      HIP_CHECK(hipMemcpyAsync(h, n->stats, sizeof h, hipMemcpyDeviceToHost, st));      // builds are rare: one blocking read each
+      HIP_CHECK(hipStreamSynchronize(st));
+      n->maxSlabAtoms = h[0]; n->maxCellAtoms = h[1] > 0 ? h[1] : 1;
+      if (n->maxCellAtoms > 512) { fprintf(stderr, "buildNeighborListGpu: %d atoms in a cell, the slab kernel takes 512\n", n->maxCellAtoms); exit(-1); }
+      n->forceRebuildFlag = 0;
+      n->nBuilds++;
+      return;
+   }
    NlView v; v.list = n->list; v.count = n->nNeighbors; v.maxNbr = n->maxNeighbors;
    hipLaunchKernelGGL(BuildNeighborList, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells, (const int*)nullptr,

@@ -200,3 +200,157 @@ void UnloadPositionBuffer(const double* __restrict__ buf, const int* __restrict_
       rx[s] = o[0]; ry[s] = o[1]; rz[s] = o[2];
    }
 }
+
+// ====================================================================================================================
+// LJ at 5 sigma: ~730 listed neighbours per atom.  Gathering them from global memory is address-rate bound (one lane address per
+// clock per CU: 5.8 ms per step at 80^3, slower than the cell kernel), so the list is split into NL_GROUPS groups of stencil cells
+// (the three x-planes of 9 cells), the workgroup of a cell stages one group's positions in the LDS at a time and the entries are
+// 16-bit indices (3 * position: the x of an {x,y,z} record) into that staging.  list16[((cell*NL_GROUPS + g) * rows + k) * cap + i], count[(cell*NL_GROUPS + g) * cap + i].
+// Measured at 80^3 (MI355X): 3.18 ms per force call with 3 groups (x-planes) and with 9 (z-columns of 3 cells, 18 KB of LDS, 8
+// workgroups per CU) alike -- in both, the lanes / waves of a workgroup need different numbers of entries from a given group
+// (an atom near a face has most of its neighbours on that side) and wait for the slowest: VALU busy 54 %, LDS 28 %.
+#ifndef NL_GROUPS
+#define NL_GROUPS 3
+#endif
+#ifndef NL_BATCH
+#define NL_BATCH 8
+#endif
+#define NL_GROUP_CELLS (27 / NL_GROUPS)
+
+struct NlSlabView {
+   unsigned short* __restrict__ list;
+   int* __restrict__ count;
+   int  rows;
+};
+
+// cell kk of group g, in the host's x-major stencil order (self at position 13) -> index into the self-first neighbour table
+__device__ __forceinline__ int groupCell(int g, int kk)
+{
+   const int p = g * NL_GROUP_CELLS + kk;
+   return p < 13 ? p + 1 : p == 13 ? 0 : p;
+}
+
+__global__ __launch_bounds__(256)
+void BuildNeighborListSlabs(const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
+                            const int* __restrict__ nAtoms, const int* __restrict__ nbr, int nCells, int cap,
+                            NlSlabView nl, double rBuild2, double* __restrict__ lastX, double* __restrict__ lastY, double* __restrict__ lastZ,
+                            int* __restrict__ stats, int* __restrict__ status)
+{
+   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int iBox = (int)(tid / cap);
+   if (iBox >= nCells) return;
+   const int i = (int)(tid - (long)iBox * cap);
+   const int ni = nAtoms[iBox];
+   if (i == 0) {                                     // staging sizes the force kernel will need: largest group, fullest cell
+      atomicMax(&stats[1], ni);
+      for (int g = 0; g < NL_GROUPS; ++g) {
+         int tot = 0;
+         for (int kk = 0; kk < NL_GROUP_CELLS; ++kk) tot += nAtoms[nbr[(size_t)iBox * 27 + groupCell(g, kk)]];
+         atomicMax(&stats[0], tot);
+      }
+   }
+   if (i >= ni) return;
+   const size_t iSlot = (size_t)iBox * cap + i;
+   const double xi = rx[iSlot], yi = ry[iSlot], zi = rz[iSlot];
+   lastX[iSlot] = xi; lastY[iSlot] = yi; lastZ[iSlot] = zi;
+   bool over = false;
+   for (int g = 0; g < NL_GROUPS; ++g) {
+      unsigned short* __restrict__ row = nl.list + ((size_t)(iBox * NL_GROUPS + g) * nl.rows) * cap + i;
+      int n = 0, off = 0;
+      for (int kk = 0; kk < NL_GROUP_CELLS; ++kk) {
+         const int jBox = nbr[(size_t)iBox * 27 + groupCell(g, kk)];
+         const int nj = nAtoms[jBox];
+         const size_t base = (size_t)jBox * cap;
+         for (int j = 0; j < nj; ++j) {
+            const double dx = xi - rx[base + j], dy = yi - ry[base + j], dz = zi - rz[base + j];
+            const double r2 = dx*dx + dy*dy + dz*dz;
+            if (r2 <= rBuild2 && base + j != iSlot) {
+               if (n < nl.rows) row[(size_t)n * cap] = (unsigned short)(3 * (off + j));      // index of the x of its {x,y,z} record
+               ++n;
+            }
+         }
+         off += nj;
+      }
+      if (n > nl.rows) { over = true; n = nl.rows; }
+      nl.count[(size_t)(iBox * NL_GROUPS + g) * cap + i] = n;
+   }
+   if (over) atomicOr(&status[3], 2);
+}
+
+// workgroup per cell, thread per atom; blockDim.x = fullest cell rounded up to whole waves (<= 512); LDS = 3 * groupAtoms doubles
+template <bool ENERGY>
+__global__ __launch_bounds__(512)
+void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
+{
+   extern __shared__ __attribute__((aligned(16))) double ldsPos[];      // {x, y, z} records: one address per neighbour, ds_read offsets 0/8/16
+   double* __restrict__ sp = ldsPos;
+   (void)groupAtoms;
+   const int iBox = a.cells ? a.cells[blockIdx.x] : blockIdx.x;
+   const int i = threadIdx.x;
+   const int ni = a.nAtoms[iBox];
+   const bool active = i < ni;
+   const size_t iSlot = (size_t)iBox * a.cap + (active ? i : 0);
+   const double xi = a.rx[iSlot], yi = a.ry[iSlot], zi = a.rz[iSlot];
+   double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+   for (int g = 0; g < NL_GROUPS; ++g) {
+      if (g) __syncthreads();                         // everyone is done reading the previous group
+      {  // all cells' loads in flight together, then the LDS stores (one global round trip per group)
+         double vx[NL_GROUP_CELLS], vy[NL_GROUP_CELLS], vz[NL_GROUP_CELLS];
+         int dst[NL_GROUP_CELLS];
+         int off = 0;
+#pragma unroll
+         for (int kk = 0; kk < NL_GROUP_CELLS; ++kk) {
+            const int jBox = a.nbr[(size_t)iBox * 27 + groupCell(g, kk)];
+            const int nj = a.nAtoms[jBox];
+            const size_t js = (size_t)jBox * a.cap + (i < nj ? i : 0);      // unconditional loads (slot 0 always exists) so they all issue at once
+            vx[kk] = a.rx[js]; vy[kk] = a.ry[js]; vz[kk] = a.rz[js];
+            dst[kk] = i < nj ? off + i : -1;
+            off += nj;
+         }
+#pragma unroll
+         for (int kk = 0; kk < NL_GROUP_CELLS; ++kk)
+            if (dst[kk] >= 0) { sp[3 * dst[kk]] = vx[kk]; sp[3 * dst[kk] + 1] = vy[kk]; sp[3 * dst[kk] + 2] = vz[kk]; }
+      }
+      __syncthreads();
+      if (active) {
+         const int n = nl.count[(size_t)(iBox * NL_GROUPS + g) * a.cap + i];
+         const unsigned short* __restrict__ row = nl.list + ((size_t)(iBox * NL_GROUPS + g) * nl.rows) * a.cap + i;
+         // NL_BATCH rows per trip, the next trip's rows already in flight (the list streams from HBM), all LDS gathers of a trip
+         // issued before the arithmetic: one LDS round trip per batch, not per pair
+         int k = 0;
+         int jn[NL_BATCH];
+         if (n >= NL_BATCH) {
+#pragma unroll
+            for (int u = 0; u < NL_BATCH; ++u) jn[u] = row[(size_t)u * a.cap];
+         }
+         for (; k + NL_BATCH <= n; k += NL_BATCH) {
+            int j[NL_BATCH];
+#pragma unroll
+            for (int u = 0; u < NL_BATCH; ++u) j[u] = jn[u];
+            if (k + 2 * NL_BATCH <= n) {
+#pragma unroll
+               for (int u = 0; u < NL_BATCH; ++u) jn[u] = row[(size_t)(k + NL_BATCH + u) * a.cap];
+            }
+            double dx[NL_BATCH], dy[NL_BATCH], dz[NL_BATCH];
+#pragma unroll
+            for (int u = 0; u < NL_BATCH; ++u) { dx[u] = xi - sp[j[u]]; dy[u] = yi - sp[j[u] + 1]; dz[u] = zi - sp[j[u] + 2]; }
+#pragma unroll
+            for (int u = 0; u < NL_BATCH; ++u) {
+               const double r2 = dx[u]*dx[u] + dy[u]*dy[u] + dz[u]*dz[u];
+               if (r2 <= a.rc2) ljPair<ENERGY>(dx[u], dy[u], dz[u], r2, a, fx, fy, fz, e);
+            }
+         }
+         for (; k < n; ++k) {
+            const int j = row[(size_t)k * a.cap];
+            const double dx = xi - sp[j], dy = yi - sp[j + 1], dz = zi - sp[j + 2];
+            const double r2 = dx*dx + dy*dy + dz*dz;
+            if (r2 <= a.rc2) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+         }
+      }
+   }
+   if (active) {
+      const double fs = 24.0 * a.eps;
+      a.fx[iSlot] = fx * fs; a.fy[iSlot] = fy * fs; a.fz[iSlot] = fz * fs;
+      if (ENERGY) a.e[iSlot] = e * 2.0 * a.eps;
+   }
+}

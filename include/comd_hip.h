@@ -71,6 +71,13 @@ typedef struct NeighborListGpu {
    vec_t  lastR;                       /* device [nLocalBoxes * maxAtoms]: positions at the last build */
    int*   updateRequired;              /* device [1] */
    real_t skinDistance, skinDistance2, skinDistanceHalf2;
+   /* LJ (cells of <= 512 slots): the list is kept per group of stencil cells (the 3 x-planes of 9 cells) as 16-bit indices into the
+    * LDS staging of that group: list16[((c*3 + g)*slabRows + k)*maxAtoms + i], nNeighbors[(c*3 + g)*maxAtoms + i]; `list` is unused */
+   int    slabFormat;                  /* 1: slab lists */
+   unsigned short* list16;
+   int    slabRows;
+   int*   stats;                       /* device [2]: {atoms in the largest group, fullest cell} at the last build */
+   int    maxSlabAtoms, maxCellAtoms;  /* host copies */
    int    forceRebuildFlag;            /* host: the next neighborListUpdateRequiredGpu answers 1 without looking */
    int    nBuilds;                     /* host: builds since AllocateGpu */
 } NeighborListGpu;
