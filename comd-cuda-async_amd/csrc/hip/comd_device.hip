@@ -187,7 +187,15 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
       if (nl->maxNeighbors > 27 * cfg->maxAtoms) nl->maxNeighbors = 27 * cfg->maxAtoms;
       const size_t localSlots = (size_t)cfg->nLocalBoxes * cfg->maxAtoms;
       nl->slabFormat = !cfg->do_eam && cfg->maxAtoms % 64 == 0 && cfg->maxAtoms <= 512 && !getenv("COMD_NL_GLOBAL");
-      if (nl->slabFormat) {
+      const bool pow2 = (cfg->maxAtoms & (cfg->maxAtoms - 1)) == 0;
+      if (cfg->do_eam && pow2 && cfg->maxAtoms <= 64 && eamCtaTableBytes(1, cfg->nRho, cfg->nPhi) <= 32 * 1024 && !getenv("COMD_NL_GLOBAL")) {
+         // EAM with LDS-sized tables: 16-bit entries into the wave's staging of the whole 27-cell stencil
+         nl->slabFormat = 2;
+         nl->slabRows = nl->maxNeighbors;
+         nl->list16 = dalloc<unsigned short>(localSlots * nl->slabRows, false);
+         nl->nNeighbors = dalloc<int>(localSlots);
+         nl->stats = dalloc<int>(2);
+      } else if (nl->slabFormat) {
          // share of the list sphere (radius R) one group can hold.  3 groups: the atom's own x-plane of cells, thickness wx, cuts at
          // most wx * pi R^2 out of 4/3 pi R^3 (78 % for cells of about R); 9 groups: its own z-column, wx * wy * 2R (51 %)
          const double R = cutoff + cfg->skinDistance;
@@ -435,7 +443,18 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
    if (num_cells <= 0) return;
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
    ForceTimer timer(st);
-   if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
+   if ((method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat == 2) {
+      NeighborListGpu* n = &sim->atoms.neighborList;
+      (void)nlView(sim);
+      NlSlabView v; v.list = n->list16; v.count = n->nNeighbors; v.rows = n->slabRows;
+      const bool sameGrid = a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+      const size_t lds = eamNlLdsBytes(STEP, a.rho.n, a.phi.n, sameGrid, n->maxSlabAtoms);
+      if (lds > 160 * 1024) { fprintf(stderr, "eamForce: %d atoms in a 27-cell stencil do not fit the LDS\n", n->maxSlabAtoms); exit(-1); }
+      static size_t attrSet = 0;
+      if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_nl_lds<STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+      const int grid = ceilDiv(num_cells, EAM_NL_WAVES * 8);        // each wave walks ~8 consecutive cells
+      hipLaunchKernelGGL(EAM_Force_nl_lds<STEP>, dim3(grid), dim3(64 * EAM_NL_WAVES), lds, st, a, v, n->maxSlabAtoms);
+   } else if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
       const NlView nl = nlView(sim);
       const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
       const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
@@ -649,7 +668,7 @@ extern "C" void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d
 extern "C" void emptyNeighborListGpu(SimGpu* sim, int)
 {
    NeighborListGpu* n = &sim->atoms.neighborList;
-   if (n->nNeighbors) HIP_CHECK(hipMemsetAsync(n->nNeighbors, 0, (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * (n->slabFormat ? NL_GROUPS : 1) * sizeof(int), S(sim->boundary_stream)));
+   if (n->nNeighbors) HIP_CHECK(hipMemsetAsync(n->nNeighbors, 0, (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * (n->slabFormat == 1 ? NL_GROUPS : 1) * sizeof(int), S(sim->boundary_stream)));
 }
 
 extern "C" void neighborListForceRebuildGpu(SimGpu* sim) { sim->atoms.neighborList.forceRebuildFlag = 1; }
@@ -678,6 +697,11 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
       hipStream_t st = S(sim->boundary_stream);
       NlSlabView sv; sv.list = n->list16; sv.count = n->nNeighbors; sv.rows = n->slabRows;
       HIP_CHECK(hipMemsetAsync(n->stats, 0, 2 * sizeof(int), st));
+      if (n->slabFormat == 2)
+         hipLaunchKernelGGL(BuildNeighborListCell16, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
+                            sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
+                            sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);
+      else
       hipLaunchKernelGGL(BuildNeighborListSlabs, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
                          sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
                          sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);
@@ -686,7 +710,7 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
       HIP_CHECK(hipMemcpyAsync(h, n->stats, sizeof h, hipMemcpyDeviceToHost, st));      // builds are rare: one blocking read each
       HIP_CHECK(hipStreamSynchronize(st));
       n->maxSlabAtoms = h[0]; n->maxCellAtoms = h[1] > 0 ? h[1] : 1;
-      if (n->maxCellAtoms > 512) { fprintf(stderr, "buildNeighborListGpu: %d atoms in a cell, the slab kernel takes 512\n", n->maxCellAtoms); exit(-1); }
+      if (n->slabFormat == 1 && n->maxCellAtoms > 512) { fprintf(stderr, "buildNeighborListGpu: %d atoms in a cell, the slab kernel takes 512\n", n->maxCellAtoms); exit(-1); }
       n->forceRebuildFlag = 0;
       n->nBuilds++;
       return;

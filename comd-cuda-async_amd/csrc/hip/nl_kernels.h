@@ -354,3 +354,236 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
       if (ENERGY) a.e[iSlot] = e * 2.0 * a.eps;
    }
 }
+
+// ====================================================================================================================
+// EAM: ~57 listed neighbours per atom (Cu_u6, skin 10 %), ~14 atoms per cell: the whole 27-cell stencil is 373 atoms, 9-12 KB as
+// {x,y,z[,F']} records, so ONE WAVE stages it in its own LDS slice and walks the lists of its cell with no barrier at all.
+// Lanes: 4 per atom (lane = 4*i + q takes rows k = q, q+4, ... of atom i; a quad-permute DPP sum joins them), 16 atoms per round.
+// Entries are 16-bit record numbers in staging order (the self-first neighbour table, each cell's atoms in slot order).
+// list16[(cell * rows + k) * cap + i], count[cell * cap + i].  cap is a power of two <= 64 (chooseMaxAtoms for EAM).
+#define EAM_NL_WAVES 4
+
+__global__ __launch_bounds__(256)
+void BuildNeighborListCell16(const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
+                             const int* __restrict__ nAtoms, const int* __restrict__ nbr, int nCells, int cap,
+                             NlSlabView nl, double rBuild2, double* __restrict__ lastX, double* __restrict__ lastY, double* __restrict__ lastZ,
+                             int* __restrict__ stats, int* __restrict__ status)
+{
+   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int iBox = (int)(tid / cap);
+   if (iBox >= nCells) return;
+   const int i = (int)(tid - (long)iBox * cap);
+   const int ni = nAtoms[iBox];
+   if (i == 0) {
+      int tot = 0;
+      for (int k = 0; k < 27; ++k) tot += nAtoms[nbr[(size_t)iBox * 27 + k]];
+      atomicMax(&stats[0], tot);
+      atomicMax(&stats[1], ni);
+   }
+   if (i >= ni) return;
+   const size_t iSlot = (size_t)iBox * cap + i;
+   const double xi = rx[iSlot], yi = ry[iSlot], zi = rz[iSlot];
+   lastX[iSlot] = xi; lastY[iSlot] = yi; lastZ[iSlot] = zi;
+   unsigned short* __restrict__ row = nl.list + ((size_t)iBox * nl.rows) * cap + i;
+   int n = 0, off = 0;
+   for (int k = 0; k < 27; ++k) {
+      const int jBox = nbr[(size_t)iBox * 27 + k];
+      const int nj = nAtoms[jBox];
+      const size_t base = (size_t)jBox * cap;
+      for (int j = 0; j < nj; ++j) {
+         const double dx = xi - rx[base + j], dy = yi - ry[base + j], dz = zi - rz[base + j];
+         const double r2 = dx*dx + dy*dy + dz*dz;
+         if (r2 <= rBuild2 && base + j != iSlot) {
+            if (n < nl.rows) row[(size_t)n * cap] = (unsigned short)(off + j);
+            ++n;
+         }
+      }
+      off += nj;
+   }
+   if (n > nl.rows) { atomicOr(&status[3], 2); n = nl.rows; }
+   nl.count[iSlot] = n;
+}
+
+// quad sum: every lane of an aligned group of 4 ends with the group's total
+__device__ __forceinline__ double quadSum(double v)
+{
+   v += dppMove64<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+   v += dppMove64<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+   return v;
+}
+
+template <int STEP>
+__global__ __launch_bounds__(64 * EAM_NL_WAVES)
+void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
+{
+   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+   constexpr int REC = (STEP == 3) ? 4 : 3;                  // doubles per staged atom: x, y, z [, F']
+   const int nRhoPad = a.rho.n + 3;
+   const bool sameGrid = (STEP == 1) && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+   double* sRho = (double*)ldsRaw;                           // pass 1 on one r grid: interleaved {phi, rho}; else rho then phi
+   double* sPhi = sRho + nRhoPad;
+   const int tableDoubles = (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;
+   if (sameGrid) {
+      for (int t = threadIdx.x; t < nRhoPad; t += blockDim.x) { sRho[2 * t] = a.phi.values[t]; sRho[2 * t + 1] = a.rho.values[t]; }
+   } else {
+      for (int t = threadIdx.x; t < nRhoPad; t += blockDim.x) sRho[t] = a.rho.values[t];
+      if (STEP == 1) for (int t = threadIdx.x; t < a.phi.n + 3; t += blockDim.x) sPhi[t] = a.phi.values[t];
+   }
+   __syncthreads();
+   const TableView rhoT = makeTable(a.rho, sRho), phiT = makeTable(a.phi, sPhi);
+
+   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+   double* __restrict__ sp = (double*)ldsRaw + ((tableDoubles + 1) & ~1) + (size_t)wave * (REC * stencilAtoms + 32 + 256);
+   int* sOff = (int*)(sp + REC * stencilAtoms);              // [32]: exclusive record offsets of the 27 cells, [27] = total
+   int* sBox = sOff + 32;                                    // [32]
+   unsigned short* sEnt = (unsigned short*)(sBox + 32);      // [16][64]: the rows a lane fetched for the current round
+   const int q = lane & 3, ia = lane >> 2;                   // list part, atom of the round
+
+   // cells are dealt to waves in contiguous runs so that neighbouring cells (shared stencil lines) meet in one L2
+   const int nWaves = gridDim.x * EAM_NL_WAVES;
+   const int gw = xcdRemap(blockIdx.x, gridDim.x) * EAM_NL_WAVES + wave;
+   const int per = (a.nCells + nWaves - 1) / nWaves;
+   const int ciEnd = (gw + 1) * per < a.nCells ? (gw + 1) * per : a.nCells;
+   constexpr int CH = 16;                                    // list rows a lane keeps in flight (rows q, q+4, ..., q+60 of its atom)
+   constexpr int SR = 8;                                     // staged records a lane keeps in flight (512 per wave; larger stencils: a second, blocking trip)
+
+   // Software pipeline over the wave's cells.  While cell c is evaluated out of the LDS, the loads of cell c+1 (stencil records,
+   // list rows) are in flight into registers, and the stencil description of cell c+2 (two dependent reads: neighbour table,
+   // occupancies) is on its way: a cell costs its arithmetic, not three global round trips.
+   auto cellOf = [&](int ci) { return a.cells ? a.cells[ci] : ci; };
+   int boxB = 0, cntB = 0;                                   // description of the cell after the one being loaded
+   int boxA = 0, cntA = 0;                                   // description of the cell being loaded
+   const int ciBegin = gw * per;
+   if (ciBegin < ciEnd)     { const int c = cellOf(ciBegin);     boxA = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntA = lane < 27 ? a.nAtoms[boxA] : 0; }
+   if (ciBegin + 1 < ciEnd) { const int c = cellOf(ciBegin + 1); boxB = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntB = lane < 27 ? a.nAtoms[boxB] : 0; }
+
+   double vx[SR], vy[SR], vz[SR], vd[SR];
+   int ent[CH];
+   int nMine = 0, totalL = 0, niL = 0, iBoxL = 0;            // of the cell whose loads are in flight
+
+   // scan the description in (boxA, cntA) into sOff/sBox, then issue that cell's record and row loads
+   auto issueLoads = [&]() {
+      {
+         int incl = cntA;
+#pragma unroll
+         for (int d = 1; d < 32; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+         if (lane < 28) { sOff[lane] = incl - cntA; sBox[lane] = boxA; }      // lane 27: cnt = 0 -> sOff[27] = total
+      }
+      __builtin_amdgcn_wave_barrier();
+      totalL = uniform(sOff[27]); niL = uniform(sOff[1]); iBoxL = uniform(boxA);
+      {
+         const int ii = ia < niL ? ia : 0;
+         nMine = ia < niL ? nl.count[(size_t)iBoxL * a.cap + ii] : 0;
+         const unsigned short* __restrict__ row = nl.list + ((size_t)iBoxL * nl.rows) * a.cap + ii;
+#pragma unroll
+         for (int u = 0; u < CH; ++u) { const int k = q + 4 * u; ent[u] = k < nl.rows ? row[(size_t)k * a.cap] : 0; }      // in bounds whatever n is
+      }
+#pragma unroll
+      for (int g = 0; g < SR; ++g) {
+         const int t = g * 64 + lane;
+         const int tt = t < totalL ? t : 0;
+         int lo = 0;                                                    // largest k in [0, 26] with sOff[k] <= tt
+#pragma unroll
+         for (int step = 16; step >= 1; step >>= 1) { const int m = lo + step; if (m <= 26 && sOff[m] <= tt) lo = m; }
+         const size_t o = (size_t)sBox[lo] * a.cap + (tt - sOff[lo]);
+         vx[g] = a.rx[o]; vy[g] = a.ry[o]; vz[g] = a.rz[o];
+         if (STEP == 3) vd[g] = a.dfEmbed[o];
+      }
+   };
+   if (ciBegin < ciEnd) issueLoads();
+
+   for (int ci = ciBegin; ci < ciEnd; ++ci) {
+      // (a) the loads of cell ci have been issued: land them in the LDS
+      const int total = totalL, ni = niL, iBox = iBoxL;
+      const int n0 = nMine;
+#pragma unroll
+      for (int g = 0; g < SR; ++g) {
+         const int t = g * 64 + lane;
+         if (t < total) {
+            double* r = sp + REC * t;
+            r[0] = vx[g]; r[1] = vy[g]; r[2] = vz[g];
+            if (STEP == 3) r[3] = vd[g];
+         }
+      }
+      for (int t = SR * 64 + lane; t < total; t += 64) {     // stencils beyond 512 atoms: blocking trip (sOff/sBox still describe cell ci)
+         int lo = 0;
+#pragma unroll
+         for (int step = 16; step >= 1; step >>= 1) { const int m = lo + step; if (m <= 26 && sOff[m] <= t) lo = m; }
+         const size_t o = (size_t)sBox[lo] * a.cap + (t - sOff[lo]);
+         double* r = sp + REC * t;
+         r[0] = a.rx[o]; r[1] = a.ry[o]; r[2] = a.rz[o];
+         if (STEP == 3) r[3] = a.dfEmbed[o];
+      }
+#pragma unroll
+      for (int u = 0; u < CH; ++u) sEnt[u * 64 + lane] = (unsigned short)ent[u];
+      __builtin_amdgcn_wave_barrier();
+
+      // (b) start cell ci+1 (its description arrived during cell ci-1) and ask for the description of ci+2
+      if (ci + 1 < ciEnd) {
+         boxA = boxB; cntA = cntB;
+         if (ci + 2 < ciEnd) { const int c = cellOf(ci + 2); boxB = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntB = lane < 27 ? a.nAtoms[boxB] : 0; }
+         issueLoads();
+      }
+
+      // (c) evaluate cell ci from the LDS
+      auto fetchRows = [&](int i0, int& nOut) {              // later rounds of a cell with more than 16 atoms: blocking
+         const int i = i0 + ia;
+         const int ii = i < ni ? i : 0;
+         nOut = i < ni ? nl.count[(size_t)iBox * a.cap + ii] : 0;
+         const unsigned short* __restrict__ row = nl.list + ((size_t)iBox * nl.rows) * a.cap + ii;
+         for (int u = 0; u < CH; ++u) { const int k = q + 4 * u; sEnt[u * 64 + lane] = k < nl.rows ? row[(size_t)k * a.cap] : (unsigned short)0; }
+      };
+      for (int i0 = 0; i0 < ni; i0 += 16) {
+         int n = n0;
+         if (i0) fetchRows(i0, n);
+         const int i = i0 + ia;
+         const bool have = i < ni;
+         const int ii = have ? i : 0;
+         const double xi = sp[REC * ii], yi = sp[REC * ii + 1], zi = sp[REC * ii + 2];      // own cell is staged first: record i
+         const double dfi = (STEP == 3) ? sp[REC * ii + 3] : 0.0;
+         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0;
+         auto pairEval = [&](int j) {
+            const double* r0 = sp + REC * j;
+            const double dx = xi - r0[0], dy = yi - r0[1], dz = zi - r0[2];
+            const double r2 = dx*dx + dy*dy + dz*dz;
+            if (r2 <= a.rc2 && r2 > 0.0) {
+               const double ir = rsqrt64(r2), r = r2 * ir;
+               double rho, drho, dphi;
+               if (STEP == 1) {
+                  double phi;
+                  if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
+                  else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
+                  e += phi; rb += rho;
+               } else {
+                  interpolate(rhoT, r, rho, drho);
+                  dphi = (dfi + r0[3 % REC]) * drho;
+               }
+               dphi *= ir;
+               fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
+            }
+         };
+         const int mine = n > q ? (n - q + 3) >> 2 : 0;      // rows q, q+4, ... < n
+         for (int u = 0; u < (mine < CH ? mine : CH); ++u) pairEval(sEnt[u * 64 + lane]);
+         if (n > 4 * CH) {                                   // longer lists than the registers hold (not with the default sizing)
+            const unsigned short* __restrict__ row = nl.list + ((size_t)iBox * nl.rows) * a.cap + ii;
+            for (int k = q + 4 * CH; k < n; k += 4) pairEval(row[(size_t)k * a.cap]);
+         }
+         fx = quadSum(fx); fy = quadSum(fy); fz = quadSum(fz);
+         if (STEP == 1) { e = quadSum(e); rb = quadSum(rb); }
+         if (have && q == 0) {
+            const size_t io = (size_t)iBox * a.cap + i;
+            if (STEP == 1) { a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = 0.5 * e; a.rhobar[io] = rb; }
+            else           { a.fx[io] += fx; a.fy[io] += fy; a.fz[io] += fz; }
+         }
+      }
+      __builtin_amdgcn_wave_barrier();
+   }
+}
+
+static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, int stencilAtoms)
+{
+   const int rec = step == 3 ? 4 : 3;
+   size_t tableDoubles = step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
+   tableDoubles = (tableDoubles + 1) & ~(size_t)1;
+   return (tableDoubles + (size_t)EAM_NL_WAVES * ((size_t)rec * stencilAtoms + 32 + 256)) * sizeof(double);      // + offsets/cells + row stash
+}

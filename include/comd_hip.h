@@ -73,7 +73,8 @@ typedef struct NeighborListGpu {
    real_t skinDistance, skinDistance2, skinDistanceHalf2;
    /* LJ (cells of <= 512 slots): the list is kept per group of stencil cells (the 3 x-planes of 9 cells) as 16-bit indices into the
     * LDS staging of that group: list16[((c*3 + g)*slabRows + k)*maxAtoms + i], nNeighbors[(c*3 + g)*maxAtoms + i]; `list` is unused */
-   int    slabFormat;                  /* 1: slab lists */
+   int    slabFormat;                  /* 0: `list` of global slots; 1: LJ slab lists; 2: EAM, 16-bit record numbers into a wave's staging of the
+                                        * whole 27-cell stencil: list16[(c*slabRows + k)*maxAtoms + i], nNeighbors[c*maxAtoms + i] */
    unsigned short* list16;
    int    slabRows;
    int*   stats;                       /* device [2]: {atoms in the largest group, fullest cell} at the last build */
