@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cmath>
 #include <vector>
 
 #include "comd_hip.h"
@@ -187,8 +188,7 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
       if (nl->maxNeighbors > 27 * cfg->maxAtoms) nl->maxNeighbors = 27 * cfg->maxAtoms;
       const size_t localSlots = (size_t)cfg->nLocalBoxes * cfg->maxAtoms;
       nl->slabFormat = !cfg->do_eam && cfg->maxAtoms % 64 == 0 && cfg->maxAtoms <= 512 && !getenv("COMD_NL_GLOBAL");
-      const bool pow2 = (cfg->maxAtoms & (cfg->maxAtoms - 1)) == 0;
-      if (cfg->do_eam && pow2 && cfg->maxAtoms <= 64 && eamCtaTableBytes(1, cfg->nRho, cfg->nPhi) <= 32 * 1024 && !getenv("COMD_NL_GLOBAL")) {
+      if (cfg->do_eam && cfg->maxAtoms <= 64 && eamCtaTableBytes(1, cfg->nRho, cfg->nPhi) <= 32 * 1024 && !getenv("COMD_NL_GLOBAL")) {
          // EAM with LDS-sized tables: 16-bit entries into the wave's staging of the whole 27-cell stencil
          nl->slabFormat = 2;
          nl->slabRows = nl->maxNeighbors;
@@ -697,11 +697,16 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
       hipStream_t st = S(sim->boundary_stream);
       NlSlabView sv; sv.list = n->list16; sv.count = n->nNeighbors; sv.rows = n->slabRows;
       HIP_CHECK(hipMemsetAsync(n->stats, 0, 2 * sizeof(int), st));
-      if (n->slabFormat == 2)
-         hipLaunchKernelGGL(BuildNeighborListCell16, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
+      if (n->slabFormat == 2) {
+         // a wave stages at most `stencilCap` atoms of a 27-cell stencil: 27 full cells, or what 36 KB of LDS per wave hold
+         int stencilCap = 27 * sim->maxAtoms; if (stencilCap > 1536) stencilCap = 1536;
+         const size_t lds = (size_t)EAM_NL_WAVES * (3 * (size_t)stencilCap + 32) * sizeof(double);
+         static size_t attrSet = 0;
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)BuildNeighborListCell16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         hipLaunchKernelGGL(BuildNeighborListCell16, dim3(ceilDiv(sim->boxes.nLocalBoxes, EAM_NL_WAVES * 8)), dim3(64 * EAM_NL_WAVES), lds, st,
                             sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
-                            sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);
-      else
+                            sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status, stencilCap);
+      } else
       hipLaunchKernelGGL(BuildNeighborListSlabs, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
                          sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
                          sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);

@@ -360,48 +360,87 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
 // {x,y,z[,F']} records, so ONE WAVE stages it in its own LDS slice and walks the lists of its cell with no barrier at all.
 // Lanes: 4 per atom (lane = 4*i + q takes rows k = q, q+4, ... of atom i; a quad-permute DPP sum joins them), 16 atoms per round.
 // Entries are 16-bit record numbers in staging order (the self-first neighbour table, each cell's atoms in slot order).
-// list16[(cell * rows + k) * cap + i], count[cell * cap + i].  cap is a power of two <= 64 (chooseMaxAtoms for EAM).
+// list16[(cell * rows + k) * cap + i], count[cell * cap + i].  cap <= 64.
 #define EAM_NL_WAVES 4
 
-__global__ __launch_bounds__(256)
+// Build, same shape as the force kernel below: one wave per cell stages the stencil in its LDS slice; the four lanes of atom i test
+// four staged records per trip and a ballot packs their hits into consecutive rows (record order), so the rows q, q+4, ... each
+// lane reads back in the force kernel are an even quarter of the list.
+__global__ __launch_bounds__(64 * EAM_NL_WAVES)
 void BuildNeighborListCell16(const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
                              const int* __restrict__ nAtoms, const int* __restrict__ nbr, int nCells, int cap,
                              NlSlabView nl, double rBuild2, double* __restrict__ lastX, double* __restrict__ lastY, double* __restrict__ lastZ,
-                             int* __restrict__ stats, int* __restrict__ status)
+                             int* __restrict__ stats, int* __restrict__ status, int stencilCapacity)
 {
-   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-   const int iBox = (int)(tid / cap);
-   if (iBox >= nCells) return;
-   const int i = (int)(tid - (long)iBox * cap);
-   const int ni = nAtoms[iBox];
-   if (i == 0) {
-      int tot = 0;
-      for (int k = 0; k < 27; ++k) tot += nAtoms[nbr[(size_t)iBox * 27 + k]];
-      atomicMax(&stats[0], tot);
-      atomicMax(&stats[1], ni);
-   }
-   if (i >= ni) return;
-   const size_t iSlot = (size_t)iBox * cap + i;
-   const double xi = rx[iSlot], yi = ry[iSlot], zi = rz[iSlot];
-   lastX[iSlot] = xi; lastY[iSlot] = yi; lastZ[iSlot] = zi;
-   unsigned short* __restrict__ row = nl.list + ((size_t)iBox * nl.rows) * cap + i;
-   int n = 0, off = 0;
-   for (int k = 0; k < 27; ++k) {
-      const int jBox = nbr[(size_t)iBox * 27 + k];
-      const int nj = nAtoms[jBox];
-      const size_t base = (size_t)jBox * cap;
-      for (int j = 0; j < nj; ++j) {
-         const double dx = xi - rx[base + j], dy = yi - ry[base + j], dz = zi - rz[base + j];
-         const double r2 = dx*dx + dy*dy + dz*dz;
-         if (r2 <= rBuild2 && base + j != iSlot) {
-            if (n < nl.rows) row[(size_t)n * cap] = (unsigned short)(off + j);
-            ++n;
+   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+   double* __restrict__ sp = (double*)ldsRaw + (size_t)wave * (3 * stencilCapacity + 32);
+   int* sOff = (int*)(sp + 3 * stencilCapacity);
+   int* sBox = sOff + 32;
+   const int q = lane & 3, ia = lane >> 2;
+   const int nWaves = gridDim.x * EAM_NL_WAVES;
+   const int gw = blockIdx.x * EAM_NL_WAVES + wave;
+   const int per = (nCells + nWaves - 1) / nWaves;
+   bool over = false;
+   for (int iBox = gw * per; iBox < (gw + 1) * per && iBox < nCells; ++iBox) {
+      {
+         const int box = lane < 27 ? nbr[(size_t)iBox * 27 + lane] : 0;
+         const int cnt = lane < 27 ? nAtoms[box] : 0;
+         int incl = cnt;
+#pragma unroll
+         for (int d = 1; d < 32; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+         if (lane < 28) { sOff[lane] = incl - cnt; sBox[lane] = box; }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int total = uniform(sOff[27]), ni = uniform(sOff[1]);
+      if (lane == 0) { atomicMax(&stats[0], total); atomicMax(&stats[1], ni); }
+      if (total > stencilCapacity) { over = true; continue; }            // reported below; the lists of this cell stay empty
+      for (int t0 = 0; t0 < total; t0 += 256) {
+         double vx[4], vy[4], vz[4];
+#pragma unroll
+         for (int g = 0; g < 4; ++g) {
+            const int t = t0 + g * 64 + lane;
+            const int tt = t < total ? t : 0;
+            int lo = 0;
+#pragma unroll
+            for (int step = 16; step >= 1; step >>= 1) { const int m = lo + step; if (m <= 26 && sOff[m] <= tt) lo = m; }
+            const size_t o = (size_t)sBox[lo] * cap + (tt - sOff[lo]);
+            vx[g] = rx[o]; vy[g] = ry[o]; vz[g] = rz[o];
+         }
+#pragma unroll
+         for (int g = 0; g < 4; ++g) {
+            const int t = t0 + g * 64 + lane;
+            if (t < total) { sp[3 * t] = vx[g]; sp[3 * t + 1] = vy[g]; sp[3 * t + 2] = vz[g]; }
          }
       }
-      off += nj;
+      __builtin_amdgcn_wave_barrier();
+      for (int i0 = 0; i0 < ni; i0 += 16) {
+         const int i = i0 + ia;
+         const bool have = i < ni;
+         const int ii = have ? i : 0;
+         const size_t iSlot = (size_t)iBox * cap + ii;
+         const double xi = sp[3 * ii], yi = sp[3 * ii + 1], zi = sp[3 * ii + 2];
+         if (have && q == 0) { lastX[iSlot] = xi; lastY[iSlot] = yi; lastZ[iSlot] = zi; }
+         unsigned short* __restrict__ row = nl.list + ((size_t)iBox * nl.rows) * cap + ii;
+         int n = 0;                                          // hits of atom i so far (the same in its four lanes)
+         for (int t0 = 0; t0 < total; t0 += 4) {             // four records per trip, one per lane of the quad; rows keep record order
+            const int t = t0 + q;
+            bool hit = false;
+            if (have && t < total) {
+               const double dx = xi - sp[3 * t], dy = yi - sp[3 * t + 1], dz = zi - sp[3 * t + 2];
+               hit = dx*dx + dy*dy + dz*dz <= rBuild2 && t != i;
+            }
+            const unsigned nib = (unsigned)(__ballot(hit) >> (lane & ~3)) & 0xFu;
+            const int k = n + __popc(nib & ((1u << q) - 1u));
+            if (hit && k < nl.rows) row[(size_t)k * cap] = (unsigned short)t;
+            n += __popc(nib);
+         }
+         if (n > nl.rows) { over = true; n = nl.rows; }
+         if (have && q == 0) nl.count[iSlot] = n;
+      }
+      __builtin_amdgcn_wave_barrier();
    }
-   if (n > nl.rows) { atomicOr(&status[3], 2); n = nl.rows; }
-   nl.count[iSlot] = n;
+   if (over) atomicOr(&status[3], 2);
 }
 
 // quad sum: every lane of an aligned group of 4 ends with the group's total
@@ -562,11 +601,11 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
                fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
             }
          };
-         const int mine = n > q ? (n - q + 3) >> 2 : 0;      // rows q, q+4, ... < n
+         const int mine = n > q ? (n - q + 3) >> 2 : 0;      // this lane's rows: q, q+4, ... < n
          for (int u = 0; u < (mine < CH ? mine : CH); ++u) pairEval(sEnt[u * 64 + lane]);
-         if (n > 4 * CH) {                                   // longer lists than the registers hold (not with the default sizing)
+         if (mine > CH) {                                    // longer lists than the registers hold (not with the default sizing)
             const unsigned short* __restrict__ row = nl.list + ((size_t)iBox * nl.rows) * a.cap + ii;
-            for (int k = q + 4 * CH; k < n; k += 4) pairEval(row[(size_t)k * a.cap]);
+            for (int u = CH; u < mine; ++u) pairEval(row[(size_t)(q + 4 * u) * a.cap]);
          }
          fx = quadSum(fx); fy = quadSum(fy); fz = quadSum(fz);
          if (STEP == 1) { e = quadSum(e); rb = quadSum(rb); }

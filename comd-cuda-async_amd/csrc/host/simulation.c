@@ -48,11 +48,14 @@ static void sanityChecks(Command cmd, double cutoff, double latticeConst, char l
 /* link-cell slot capacity when the user gives none: the lattice's largest occupancy plus head-room for thermal
  * motion and the initial displacement, rounded so that waves never straddle cells (LJ: multiple of 64) or cells
  * never straddle waves (EAM: power of two). */
-static int chooseMaxAtoms(int latticeMax, real_t delta, const LinkCell* boxes, int doeam)
+static int chooseMaxAtoms(int latticeMax, real_t delta, const LinkCell* boxes, int doeam, int useNL)
 {
    real_t minBox = fmin(boxes->boxSize[0], fmin(boxes->boxSize[1], boxes->boxSize[2]));
    int want = (int)ceil(latticeMax * (1.10 + 3.0 * delta / minBox)) + 8;
    if (!doeam) return ((want + 63) / 64) * 64;
+   /* the EAM list kernels take any capacity up to 64; the cell kernels (cta_cell staging) want a power of two.  Cells of
+    * cutoff + skin hold 4..32 atoms of a perfect lattice: 44 slots instead of 64 is a third less for every slot-wise kernel */
+   if (useNL && want <= 64) return ((want + 3) / 4) * 4;
    int cap = 16;
    while (cap < want) cap *= 2;
    return cap;
@@ -133,7 +136,7 @@ SimFlat* initSimulationHost(Command cmd)
    if (cap <= 0) {
       int localMax = countFccLattice(cmd.nx, cmd.ny, cmd.nz, latticeConstant, sim->domain, sim->boxes), globalMaxOcc;
       maxIntParallel(&localMax, &globalMaxOcc, 1);
-      cap = chooseMaxAtoms(globalMaxOcc, cmd.initialDelta, sim->boxes, cmd.doeam);
+      cap = chooseMaxAtoms(globalMaxOcc, cmd.initialDelta, sim->boxes, cmd.doeam, sim->useNL);
    }
    sim->boxes->maxAtoms = cap;
    sim->atoms = initAtoms(sim->boxes);
