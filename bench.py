@@ -16,6 +16,8 @@ Extra objects on the JSON line:
                  Algorithmic bytes per atom: LJ force 56 B, EAM force (3 passes) 176 B.
   cpu_baseline : the CPU restatement (oracle/, kind "port") timed on this host's cores on a bounded sample of the same
                  workload (same potential, same density, fewer atoms and steps), rank 0 at N = 1 only.
+  variants     : N = 1 only: the same K timed steps with the other force methods (cta_cell, the Verlet-list method
+                 thread_atom_nl) and the other potential, for comparison; `value` is always the named configuration.
 """
 import argparse
 import json
@@ -35,6 +37,10 @@ GRIDS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 # LJ 5 sigma: ~4000 candidates x (3 sub + mul + 2 fma = 8 FLOP) + ~550 pairs x ~25 FLOP; EAM: 2 passes x (~283 x 8 + ~42 x ~70).
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 FORCE_FLOP = {"lj": 4000 * 8 + 550 * 25, "eam": 2 * (283 * 8 + 42 * 70)}
+# Verlet lists (skin 10 %): ~732 (LJ) / ~57 (EAM) listed neighbours take the place of the stencil candidates
+FORCE_FLOP_NL = {"lj": 732 * 8 + 550 * 25, "eam": 2 * (57 * 8 + 42 * 70)}
+KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs",
+               ("eam", "thread_atom"): "EAM_Force_thread_atom", ("eam", "cta_cell"): "EAM_Force_cta_cell", ("eam", "thread_atom_nl"): "EAM_Force_nl_lds"}
 
 
 def parse():
@@ -47,6 +53,7 @@ def parse():
     ap.add_argument("--nx", type=int, default=80, help="unit cells per GPU along each axis")
     ap.add_argument("--async-halo", type=int, default=None, help="-a flag: overlap interior force with the halo exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true", help="skip the other force methods (reported as `variants` at N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -114,7 +121,7 @@ def main():
     pkg = ge.load_package()
     if "COMD_FORCE_DEVICE" in os.environ:               # debugging aid: several ranks on one GPU
         local_rank = int(os.environ["COMD_FORCE_DEVICE"])
-    pkg.setup_gpu(local_rank, rank, verbose=(rank == 0))
+    pkg.setup_gpu(local_rank, rank, verbose=False)         # stdout carries exactly one line: the JSON
     if dist is not None:
         ids = [pkg.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
@@ -123,46 +130,53 @@ def main():
     else:
         pkg.init_parallel(0, 1, None)
 
-    args = ["-x", a.nx * px, "-y", a.nx * py, "-z", a.nx * pz, "-i", px, "-j", py, "-k", pz,
-            "-m", method, "-a", use_async] + (["-e"] if a.pot == "eam" else [])
-    sim = pkg.Simulation(args)
-    hip = pkg.lib_hip()
+    def measure(pot, meth, steps, warmup):
+        """One Simulation of `pot`/`meth`: W untimed steps, then exactly K steps between barrier + device syncs."""
+        args = ["-x", a.nx * px, "-y", a.nx * py, "-z", a.nx * pz, "-i", px, "-j", py, "-k", pz,
+                "-m", meth, "-a", use_async] + (["-e"] if pot == "eam" else [])
+        sim = pkg.Simulation(args)
 
-    def sync_all():
-        hip.comdDeviceSynchronize()
+        def sync_all():
+            hip.comdDeviceSynchronize()
+            if dist is not None:
+                dist.barrier()
+            hip.comdDeviceSynchronize()
+
+        sim.step(warmup)
+        sync_all()
+        hip.comdForceTimingEnable(1)
+        hip.comdForceTimingReset()
+        builds0 = sim.nl_builds
+        t0 = time.perf_counter()
+        sim.step(steps)
+        sync_all()
+        elapsed = time.perf_counter() - t0
+        n_launch = ctypes.c_int(0)
+        force_ms = hip.comdForceTimingTotalMs(ctypes.byref(n_launch))
+        hip.comdForceTimingEnable(0)
         if dist is not None:
-            dist.barrier()
-        hip.comdDeviceSynchronize()
+            import torch
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t[0])
+        ep, ek, n_global = sim.energy()
+        sim.sum_atoms()
+        assert sim.energy()[2] == n_global, "atoms were lost"
+        res = {"elapsed": elapsed, "force_ms": force_ms, "launches": int(n_launch.value), "ep": ep, "ek": ek, "n_global": n_global,
+               "cap": sim.max_atoms, "nl_builds": sim.nl_builds - builds0}
+        sim.close()
+        return res
 
-    sim.step(a.warmup)
-    sync_all()
-    hip.comdForceTimingEnable(1)
-    hip.comdForceTimingReset()
-    t0 = time.perf_counter()
-    sim.step(a.steps)
-    hip.comdDeviceSynchronize()
-    if dist is not None:
-        dist.barrier()
-    hip.comdDeviceSynchronize()
-    elapsed = time.perf_counter() - t0
     import ctypes
-    n_launch = ctypes.c_int(0)
-    force_ms = hip.comdForceTimingTotalMs(ctypes.byref(n_launch))
-    hip.comdForceTimingEnable(0)
-
-    if dist is not None:
-        import torch
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t[0])
-    ep, ek, n_global = sim.energy()
-    sim.sum_atoms()
-    assert sim.energy()[2] == n_global, "atoms were lost"
+    hip = pkg.lib_hip()
+    m = measure(a.pot, method, a.steps, a.warmup)
+    elapsed, force_ms, n_global, ep, ek = m["elapsed"], m["force_ms"], m["n_global"], m["ep"], m["ek"]
 
     if rank == 0:
         n_local = n_global / a.gpus
         value = n_global * a.steps / elapsed
         force_per_step_ms = force_ms / a.steps                 # all force launches of one step on rank 0
+        flop = (FORCE_FLOP_NL if method.endswith("_nl") else FORCE_FLOP)[a.pot]
         achieved = FORCE_BYTES[a.pot] * n_local / (force_per_step_ms * 1e-3) / 1e9 if force_ms > 0 else None
         out = {
             "metric": "atom_updates_per_sec", "value": value, "unit": "atom-updates/s",
@@ -170,26 +184,41 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.pot.upper()} Cu FCC {a.nx}^3 unit cells per GPU ({int(n_local)} atoms/GPU, {n_global} total), "
                                    f"{method} kernel, fp64, T=600 K, dt=1 fs",
-                       "decomposition": f"{px}x{py}x{pz}", "halo_overlap": bool(use_async), "cell_capacity": sim.max_atoms,
+                       "decomposition": f"{px}x{py}x{pz}", "halo_overlap": bool(use_async), "cell_capacity": m["cap"],
                        **({"transport": "rccl-loopback"} if loopback else {})},
             "per_gpu_value": value / a.gpus,
             "energy_per_atom_eV": (ep + ek) / n_global,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
                          "traffic": measured_traffic(a.pot, method, a.nx) if a.gpus == 1 else None,
-                         "kernel": ("LJ_Force_" if a.pot == "lj" else "EAM_Force_") + method,
-                         "kernel_ms_per_step": force_per_step_ms, "launches_timed": int(n_launch.value),
+                         "kernel": KERNEL_NAME[(a.pot, method)],
+                         "kernel_ms_per_step": force_per_step_ms, "launches_timed": m["launches"],
                          "algorithmic_bytes_per_atom": FORCE_BYTES[a.pot],
                          "whole_step_achieved_GBs": STEP_BYTES[a.pot] * value / a.gpus / 1e9,
-                         "fp64_vector": {"achieved_TFLOPs": FORCE_FLOP[a.pot] * n_local / (force_per_step_ms * 1e-3) / 1e12 if force_ms > 0 else None,
-                                         "peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "flop_per_atom": FORCE_FLOP[a.pot],
-                                         "frac": FORCE_FLOP[a.pot] * n_local / (force_per_step_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if force_ms > 0 else None},
+                         "fp64_vector": {"achieved_TFLOPs": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 if force_ms > 0 else None,
+                                         "peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "flop_per_atom": flop,
+                                         "frac": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if force_ms > 0 else None},
                          "note": "fp64 ALU-bound stencil: ~4000 (LJ) / ~283 (EAM) candidate pairs per atom against 56 / 176 algorithmic bytes (SURVEY.md 8d)"},
         }
+        if method == "thread_atom_nl":
+            out["config"]["neighbor_list_builds_timed"] = m["nl_builds"]
+    # the other force methods on the same workload (one GPU only): not the headline, reported beside it
+    variants = []
+    if a.gpus == 1 and not a.no_variants:
+        for pot, meth in (("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("lj", "cta_cell"), ("eam", "cta_cell"), ("eam", "thread_atom_nl"), ("eam", "thread_atom")):
+            if (pot, meth) == (a.pot, method):
+                continue
+            v = measure(pot, meth, a.steps, a.warmup)
+            variants.append({"workload": f"{pot.upper()} Cu FCC {a.nx}^3, {meth}", "value": v["n_global"] * a.steps / v["elapsed"],
+                             "ms_per_step": 1e3 * v["elapsed"] / a.steps, "force_ms_per_step": v["force_ms"] / a.steps,
+                             "energy_per_atom_eV": (v["ep"] + v["ek"]) / v["n_global"], "cell_capacity": v["cap"],
+                             **({"neighbor_list_builds_timed": v["nl_builds"]} if meth.endswith("_nl") else {})})
+    if rank == 0:
+        if variants:
+            out["variants"] = variants
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.pot, a.cpu_seconds)
         print(json.dumps(out))
-    sim.close()
     if dist is not None:
         dist.barrier()
         pkg.lib_hip().comdCommFinalize()
