@@ -707,9 +707,15 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
                             sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
                             sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status, stencilCap);
       } else
-      hipLaunchKernelGGL(BuildNeighborListSlabs, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
-                         sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
-                         sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);
+      {
+         // one workgroup per cell, a thread per slot; the LDS holds a whole group of full cells (<= 9 * 512 atoms = 108 KB)
+         const size_t lds = (size_t)3 * NL_GROUP_CELLS * sim->maxAtoms * sizeof(double);
+         static size_t attrSet = 0;
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)BuildNeighborListSlabs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         hipLaunchKernelGGL(BuildNeighborListSlabs, dim3(sim->boxes.nLocalBoxes), dim3(sim->maxAtoms), lds, st,
+                            sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
+                            sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);
+      }
       LAUNCH_CHECK();
       int h[2];
       HIP_CHECK(hipMemcpyAsync(h, n->stats, sizeof h, hipMemcpyDeviceToHost, st));      // builds are rare: one blocking read each
