@@ -199,7 +199,8 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
          // share of the list sphere (radius R) one group can hold.  3 groups: the atom's own x-plane of cells, thickness wx, cuts at
          // most wx * pi R^2 out of 4/3 pi R^3 (78 % for cells of about R); 9 groups: its own z-column, wx * wy * 2R (51 %)
          const double R = cutoff + cfg->skinDistance;
-         double share = NL_GROUPS == 3 ? 3.0 * cfg->boxSize[0] / (4.0 * R)
+         double share = NL_DIAGONAL ? 0.62                     // own cell + edge cells; measured 0.44-0.5 of the list for cells of about R
+                      : NL_GROUPS == 3 ? 3.0 * cfg->boxSize[0] / (4.0 * R)
                                        : 3.0 * cfg->boxSize[0] * cfg->boxSize[1] / (2.0 * 3.14159265358979 * R * R);
          if (share > 1.0) share = 1.0;
          nl->slabRows = ((int)(share * nl->maxNeighbors) + 7) / 8 * 8;

@@ -203,12 +203,10 @@ void UnloadPositionBuffer(const double* __restrict__ buf, const int* __restrict_
 
 // ====================================================================================================================
 // LJ at 5 sigma: ~730 listed neighbours per atom.  Gathering them from global memory is address-rate bound (one lane address per
-// clock per CU: 5.8 ms per step at 80^3, slower than the cell kernel), so the list is split into NL_GROUPS groups of stencil cells
-// (the three x-planes of 9 cells), the workgroup of a cell stages one group's positions in the LDS at a time and the entries are
-// 16-bit indices (3 * position: the x of an {x,y,z} record) into that staging.  list16[((cell*NL_GROUPS + g) * rows + k) * cap + i], count[(cell*NL_GROUPS + g) * cap + i].
-// Measured at 80^3 (MI355X): 3.18 ms per force call with 3 groups (x-planes) and with 9 (z-columns of 3 cells, 18 KB of LDS, 8
-// workgroups per CU) alike -- in both, the lanes / waves of a workgroup need different numbers of entries from a given group
-// (an atom near a face has most of its neighbours on that side) and wait for the slowest: VALU busy 54 %, LDS 28 %.
+// clock per CU: 5.8 ms per step at 80^3, slower than the cell kernel), so the list is split into NL_GROUPS groups of 9 stencil
+// cells (groupCell below), the workgroup of a cell stages one group's positions in the LDS at a time and the entries are
+// 16-bit indices (3 * position: the x of an {x,y,z} record) into that staging.
+// list16[((cell*NL_GROUPS + g) * rows + k) * cap + i], count[(cell*NL_GROUPS + g) * cap + i].
 #ifndef NL_GROUPS
 #define NL_GROUPS 3
 #endif
@@ -223,11 +221,25 @@ struct NlSlabView {
    int  rows;
 };
 
-// cell kk of group g, in the host's x-major stencil order (self at position 13) -> index into the self-first neighbour table
+// Cell kk of group g, as an index into the self-first neighbour table.  With NL_DIAGONAL the three groups are the classes of
+// (dx + dy + dz) mod 3 of the stencil offsets: each holds near and far cells alike (group 0: the cell itself, six edge and two
+// corner neighbours; groups 1 and 2: three face, three edge and three corner neighbours each), so every atom finds a similar share of
+// its list in every group wherever it sits in its cell, and neither the lanes of a wave nor the waves of a workgroup wait for each
+// other at the per-group barriers (x-plane groups: an atom near a face has most of its list on that side; 2.41 ms per force call at
+// 80^3 against 2.06 ms with these).
+#ifndef NL_DIAGONAL
+#define NL_DIAGONAL (NL_GROUPS == 3)
+#endif
 __device__ __forceinline__ int groupCell(int g, int kk)
 {
-   const int p = g * NL_GROUP_CELLS + kk;
+#if NL_DIAGONAL
+   // positions p = 9a + 3b + c with (a + b + c) % 3 == g, mapped through p -> (p < 13 ? p + 1 : p == 13 ? 0 : p)
+   constexpr unsigned char tab[3][9] = { { 1, 6, 8, 12, 0, 15, 19, 21, 26 }, { 2, 4, 9, 10, 14, 16, 20, 22, 24 }, { 3, 5, 7, 11, 13, 17, 18, 23, 25 } };
+   return tab[g][kk];
+#else
+   const int p = g * NL_GROUP_CELLS + kk;              // x-major stencil order (self at position 13): x-planes (3 groups) or z-columns (9)
    return p < 13 ? p + 1 : p == 13 ? 0 : p;
+#endif
 }
 
 // Build: workgroup per cell, thread per atom, the same staging as the force kernel; every thread walks the staged records of the
