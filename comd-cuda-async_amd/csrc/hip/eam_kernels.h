@@ -236,55 +236,67 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 
       const int nTiles = (nCand + 63) >> 6;
 
-      // (4)+(5) two i atoms per round
+      // (4)+(5) two i atoms per round, side by side: one read of each candidate serves both distance tests, and the two accepted-pair
+      // evaluations are one branch-free block (a lane without a pair evaluates r = cutoff, weighted 0), i.e. two independent chains of
+      // LDS table reads and fp64 arithmetic per lane
       for (int i0 = 0; i0 < ni; i0 += 2) {
          double part[2][NV];
 #pragma unroll
-         for (int u = 0; u < 2; ++u) {
+         for (int u = 0; u < 2; ++u)
 #pragma unroll
             for (int v = 0; v < NV; ++v) part[u][v] = 0.0;
-            const int i = i0 + u;
-            unsigned short* q = qBase + u * EAM_CTA_QUEUE;
-            if (i < ni) {                                             // wave-uniform
-               const double xi = sx[i], yi = sy[i], zi = sz[i];
-               const double dfi = (STEP == 3) ? a.dfEmbed[(size_t)iBox * a.cap + i] : 0.0;
-               int qn = 0;
-               for (int t = 0; t < nTiles; ++t) {
-                  const int c = t * 64 + lane;
-                  const int cc = c < nCand ? c : 0;                  // lanes past the list re-read candidate 0 and are masked
-                  const double dx = xi - sx[cc], dy = yi - sy[cc], dz = zi - sz[cc];
-                  const double r2 = dx*dx + dy*dy + dz*dz;
-                  const bool hit = (r2 <= a.rc2) && (r2 > 0.0) && (c < nCand);
-                  const unsigned long long m = __ballot(hit);
-                  if (hit) q[qn + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u))] = (unsigned short)(t * 64 + lane);
-                  qn += __popcll(m);
-               }
-               // More neighbours inside the cutoff than the queue holds (3x FCC Cu): the excess went into the next queue / past
-               // the LDS allocation (dropped by the hardware); the results are void, the flag makes comdCheckStatus stop the run.
-               // (reported once, after the cell walk: a store in here costs 4 % -- the loads behind it lose their freedom to move)
-               if (qn > EAM_CTA_QUEUE) { overrun = 1; qn = EAM_CTA_QUEUE; }
-               // accepted pairs, 64 per batch (FCC Cu: 42 neighbours inside the Cu_u6 cutoff, 54 inside Mishin's -> one batch)
-               for (int b = 0; b < qn; b += 64) {
-                  if (b + lane < qn) {
-                     const int jj = q[b + lane];
-                     const double dx = xi - sx[jj], dy = yi - sy[jj], dz = zi - sz[jj];
-                     const double r2 = dx*dx + dy*dy + dz*dz;
-                     const double ir = rsqrt64(r2), r = r2 * ir;
-                     double rho, drho, dphi;
-                     if (STEP == 1) {
-                        double phi;
-                        if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
-                        else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
-                        part[u][3] += phi; part[u][4] += rho;
-                     } else {
-                        interpolate(rhoT, r, rho, drho);
-                        dphi = (dfi + a.dfEmbed[sSlot[jj]]) * drho;
-                     }
-                     dphi *= ir;
-                     part[u][0] -= dphi * dx; part[u][1] -= dphi * dy; part[u][2] -= dphi * dz;
-                  }
-               }
+         const bool twoAtoms = i0 + 1 < ni;                          // wave-uniform
+         const int iA = i0, iB = twoAtoms ? i0 + 1 : i0;
+         const double xA = sx[iA], yA = sy[iA], zA = sz[iA];
+         const double xB = sx[iB], yB = sy[iB], zB = sz[iB];
+         const double dfA = (STEP == 3) ? a.dfEmbed[(size_t)iBox * a.cap + iA] : 0.0;
+         const double dfB = (STEP == 3) ? a.dfEmbed[(size_t)iBox * a.cap + iB] : 0.0;
+         unsigned short* qA = qBase;
+         unsigned short* qB = qBase + EAM_CTA_QUEUE;
+         int qnA = 0, qnB = 0;
+         for (int t = 0; t < nTiles; ++t) {
+            const int c = t * 64 + lane;
+            const int cc = c < nCand ? c : 0;                        // lanes past the list re-read candidate 0 and are masked
+            const double px = sx[cc], py = sy[cc], pz = sz[cc];
+            const double ax = xA - px, ay = yA - py, az = zA - pz;
+            const double bx = xB - px, by = yB - py, bz = zB - pz;
+            const double r2A = ax*ax + ay*ay + az*az, r2B = bx*bx + by*by + bz*bz;
+            const bool hitA = (r2A <= a.rc2) && (r2A > 0.0) && (c < nCand);
+            const bool hitB = twoAtoms && (r2B <= a.rc2) && (r2B > 0.0) && (c < nCand);
+            const unsigned long long mA = __ballot(hitA), mB = __ballot(hitB);
+            if (hitA) qA[qnA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u))] = (unsigned short)c;
+            if (hitB) qB[qnB + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u))] = (unsigned short)c;
+            qnA += __popcll(mA); qnB += __popcll(mB);
+         }
+         // More neighbours inside the cutoff than a queue holds (3x FCC Cu): the excess went into the next queue / past the LDS
+         // allocation (dropped by the hardware); the results are void, the flag makes comdCheckStatus stop the run.
+         // (reported once, after the cell walk: a store in here costs 4 % -- the loads behind it lose their freedom to move)
+         if (qnA > EAM_CTA_QUEUE) { overrun = 1; qnA = EAM_CTA_QUEUE; }
+         if (qnB > EAM_CTA_QUEUE) { overrun = 1; qnB = EAM_CTA_QUEUE; }
+         // accepted pairs, 64 per batch and atom (FCC Cu: 42 neighbours inside the Cu_u6 cutoff, 54 inside Mishin's -> one batch)
+         const int qnMax = qnA > qnB ? qnA : qnB;
+         for (int b = 0; b < qnMax; b += 64) {
+            const bool hA = b + lane < qnA, hB = b + lane < qnB;
+            const int jA = hA ? qA[b + lane] : iA, jB = hB ? qB[b + lane] : iB;      // no pair: the atom itself (r2 = 0), replaced by the cutoff below
+            const double ax = xA - sx[jA], ay = yA - sy[jA], az = zA - sz[jA];
+            const double bx = xB - sx[jB], by = yB - sy[jB], bz = zB - sz[jB];
+            const double sA = hA ? ax*ax + ay*ay + az*az : a.rc2, sB = hB ? bx*bx + by*by + bz*bz : a.rc2;
+            const double irA = rsqrt64(sA), irB = rsqrt64(sB);
+            const double rA = sA * irA, rB = sB * irB;
+            double rhoA, drhoA, dphiA, rhoB, drhoB, dphiB;
+            if (STEP == 1) {
+               double phiA, phiB;
+               if (sameGrid) { interpolatePair(sRho, rhoT, rA, phiA, dphiA, rhoA, drhoA); interpolatePair(sRho, rhoT, rB, phiB, dphiB, rhoB, drhoB); }
+               else { interpolate(rhoT, rA, rhoA, drhoA); interpolate(phiT, rA, phiA, dphiA); interpolate(rhoT, rB, rhoB, drhoB); interpolate(phiT, rB, phiB, dphiB); }
+               part[0][3] += hA ? phiA : 0.0; part[0][4] += hA ? rhoA : 0.0;
+               part[1][3] += hB ? phiB : 0.0; part[1][4] += hB ? rhoB : 0.0;
+            } else {
+               interpolate(rhoT, rA, rhoA, drhoA); interpolate(rhoT, rB, rhoB, drhoB);
+               dphiA = (dfA + a.dfEmbed[sSlot[jA]]) * drhoA; dphiB = (dfB + a.dfEmbed[sSlot[jB]]) * drhoB;
             }
+            dphiA = hA ? dphiA * irA : 0.0; dphiB = hB ? dphiB * irB : 0.0;
+            part[0][0] -= dphiA * ax; part[0][1] -= dphiA * ay; part[0][2] -= dphiA * az;
+            part[1][0] -= dphiB * bx; part[1][1] -= dphiB * by; part[1][2] -= dphiB * bz;
          }
          // two-atom reduction (permlane32 swap + DPP): lane 31 holds the totals of atom i0, lane 63 those of atom i0 + 1
          double tot[NV];
