@@ -102,8 +102,10 @@ def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async):
     import torch
     pkg.setup_gpu(0, rank)
     args = ["-x", n, "-y", n, "-z", n, "-i", grid[0], "-j", grid[1], "-k", grid[2], "-r", 0.1, "-m", method, "-a", use_async] + (["-e"] if eam else [])
+    if method.endswith("_nl") and not eam:
+        args += ["-S", 0.03]                                 # LJ: the default skin (1.16 A) outlasts the test; 0.35 A does not
     sim = pkg.Simulation(args)
-    steps = 12
+    steps = 40 if method.endswith("_nl") else 12          # list mode: long enough for several list builds and for atoms to change owner
 
     def gather_all(which):
         a = torch.from_numpy(sim.gather(which))
@@ -130,6 +132,8 @@ def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async):
         assert np.abs(d).max() < 1e-10
         assert np.abs(f1 - fo).max() < 1e-9 * np.abs(fo).max()
         assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < 2e-12
+        if method.endswith("_nl"):
+            assert 1 < sim.nl_builds < steps, sim.nl_builds
         print(f"gpu-mode OK: {world} ranks {grid}, {'EAM' if eam else 'LJ'} {n}^3 {method} async={use_async}: E/atom {(e1[0]+e1[1])/e1[2]:.12f}")
     sim.close()
 
