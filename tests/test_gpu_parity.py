@@ -147,6 +147,37 @@ def test_neighbor_list_trace_matches_reference(gpu, key, skin):
         assert sim.energy()[2] == 4 * ref["nx"] ** 3
 
 
+@pytest.mark.parametrize("eam,n,extra", [(0, 12, ()), (1, 8, ()), (1, 8, ("-t", "setfl", "-p", "Cu01.eam.alloy"))])
+def test_neighbor_list_global_slot_format(gpu, orc, monkeypatch, eam, n, extra):
+    """The plain list format (32-bit global slots, neighbours gathered from global memory) is what cells too large for the LDS
+    kernels and EAM tables too large for the LDS (setfl) fall back to; COMD_NL_GLOBAL=1 selects it for any run."""
+    if not extra:
+        monkeypatch.setenv("COMD_NL_GLOBAL", "1")
+    with gpu.Simulation(_args(n, eam, 0.1, "thread_atom_nl", list(extra))) as sim:
+        o = orc.Oracle(n, eam=eam, delta=0.1, **({"pot_name": "Cu01.eam.alloy"} if extra else {}))
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
+        sim.step(25)
+        o.step(25)
+        (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
+        assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
+
+
+def test_neighbor_list_80_cubed_properties(gpu):
+    """Full size (BASELINE configs[1] workload) with lists: recorded step-0 energy, conservation, nothing lost, lists reused."""
+    ref = S["lj_80_8ranks"]
+    with gpu.Simulation(_args(80, 0, 0.0, "thread_atom_nl")) as sim:
+        e0, u0, _ = _per_atom(sim)
+        assert abs(u0 - ref["step0"]["U"]) < 1e-10
+        sim.step(20)
+        e1 = _per_atom(sim)[0]
+        assert abs(e1 - ref["E_at"]["20"]) < TOL["energy_per_atom_trace"] * 2      # the reference's 8-rank CPU run
+        assert abs(e1 - e0) < 2e-5
+        assert sim.nl_builds == 1
+        sim.sum_atoms()
+        assert sim.energy()[2] == 4 * 80 ** 3
+
+
 SETFL = ["-t", "setfl", "-p", "Cu01.eam.alloy"]
 
 
