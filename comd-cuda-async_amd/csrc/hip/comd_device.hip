@@ -134,6 +134,16 @@ static void uploadTable(InterpolationObjectGpu* t, int n, real_t x0, real_t invD
    HIP_CHECK(hipMemcpy(t->values, hostValues, ((size_t)n + 3) * sizeof(real_t), hipMemcpyHostToDevice));
 }
 
+extern "C" void initLinkCellsGpu(LinkCellGpu* b, const GpuConfig* cfg)
+{
+   b->nLocalBoxes = cfg->nLocalBoxes; b->nTotalBoxes = cfg->nTotalBoxes;
+   for (int a = 0; a < 3; ++a) {
+      b->gridSize[a] = cfg->gridSize[a]; b->localMin[a] = cfg->localMin[a]; b->localMax[a] = cfg->localMax[a];
+      b->invBoxSize[a] = 1.0 / cfg->boxSize[a];
+   }
+   b->nAtoms = dalloc<int>(cfg->nTotalBoxes);
+}
+
 extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
 {
    memset(sim, 0, sizeof(*sim));
@@ -145,14 +155,8 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
    if (cfg->maxAtoms < 1 || cfg->maxAtoms > 1024) { fprintf(stderr, "AllocateGpu: maxAtoms %d outside [1,1024]\n", cfg->maxAtoms); exit(-1); }
    if (!cfg->do_eam && (cfg->maxAtoms % 64) != 0) { fprintf(stderr, "AllocateGpu: LJ needs maxAtoms %% 64 == 0 (got %d)\n", cfg->maxAtoms); exit(-1); }
 
-   LinkCellGpu* b = &sim->boxes;
-   b->nLocalBoxes = cfg->nLocalBoxes; b->nTotalBoxes = cfg->nTotalBoxes;
-   for (int a = 0; a < 3; ++a) {
-      b->gridSize[a] = cfg->gridSize[a]; b->localMin[a] = cfg->localMin[a]; b->localMax[a] = cfg->localMax[a];
-      b->invBoxSize[a] = 1.0 / cfg->boxSize[a];
-   }
+   initLinkCellsGpu(&sim->boxes, cfg);
    const size_t slots = (size_t)cfg->nTotalBoxes * cfg->maxAtoms;      // 64-bit: 256^3 LJ needs 136 M slots
-   b->nAtoms = dalloc<int>(cfg->nTotalBoxes);
    AtomsGpu* at = &sim->atoms;
    at->r.x = dalloc<real_t>(slots); at->r.y = dalloc<real_t>(slots); at->r.z = dalloc<real_t>(slots);
    at->p.x = dalloc<real_t>(slots); at->p.y = dalloc<real_t>(slots); at->p.z = dalloc<real_t>(slots);
@@ -737,6 +741,20 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
 }
 
 extern "C" int pairlistUpdateRequiredGpu(SimGpu*) { return 1; }
+
+// the reference keeps a gid -> slot hash table for its list mode (hashTable.c); here atoms keep their slots between builds
+extern "C" void initHashTableGpu(HashTableGpu* hashTable, int nMaxEntries) { if (hashTable) { hashTable->nMaxEntries = nMaxEntries; hashTable->nEntriesPut = hashTable->nEntriesGet = 0; } }
+extern "C" void emptyHashTableGpu(HashTableGpu* hashTable) { if (hashTable) hashTable->nEntriesPut = hashTable->nEntriesGet = 0; }
+
+// comm.h:40-74 (libmp / GPUDirect-Async): not part of this library -- "not in use" answers so that the reference's host objects take
+// their plain send/receive path (haloExchange.c:726-730), which include/comd_hip.h serves through CommTransport
+extern "C" int  comm_use_comm(void) { return 0; }
+extern "C" int  comm_use_gdrdma(void) { return 0; }
+extern "C" int  comm_use_async(void) { return 0; }
+extern "C" int  comm_use_gpu_comm(void) { return 0; }
+extern "C" int  comm_select_device(int mpiRank) { (void)mpiRank; return 0; }
+extern "C" int  comm_init(...) { return 0; }
+extern "C" void comm_finalize(void) {}
 
 extern "C" void loadPositionBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, const real_t shift[3], SimGpu* sim, comdStream_t stream)
 {

@@ -61,6 +61,8 @@ static int chooseMaxAtoms(int latticeMax, real_t delta, const LinkCell* boxes, i
    return cap;
 }
 
+static int cmpInt(const void* a, const void* b) { return (*(const int*)a > *(const int*)b) - (*(const int*)a < *(const int*)b); }
+
 /* gpu_utility.c:73-163 SetBoundaryCells, host half: ring 1 = local cells that touch the halo, ring 2 = their local
  * neighbours; "boundary" = ring 1 + ring 2, "interior" = the rest. */
 void setBoundaryCellsHost(SimFlat* sim, HaloExchange* hh)
@@ -85,6 +87,9 @@ void setBoundaryCellsHost(SimFlat* sim, HaloExchange* hh)
       for (int j = 0; j < 27; ++j) if (nbr[j] < n && type[nbr[j]] == 1) { type[i] = 2; sim->boundary_cells_h[nb++] = i; break; }
    }
    for (int i = 0; i < n; ++i) if (type[i] == 0) sim->interior_cells_h[ni++] = i;
+   /* both rings in one ascending run: list neighbours are then spatial neighbours, which is what the kernels' contiguous
+    * per-XCD ranges and the scalar cache want */
+   qsort(sim->boundary_cells_h, (size_t)nb, sizeof(int), cmpInt);
    sim->n_boundary1_cells = n1; sim->n_boundary_cells = nb;
    free(type);
    SetBoundaryCells(&sim->gpu, nb, sim->boundary_cells_h, ni, sim->interior_cells_h, n1, sim->boundary1_cells_h);

@@ -164,6 +164,8 @@ void GetDataFromGpu(SimGpu* sim, HostAtoms* host);
 void updateNAtomsCpu(SimGpu* sim, int* nAtomsHost);
 /* DestroyGpu(SimFlat*), gpu_utility.c:284-347 */
 void DestroyGpu(SimGpu* sim);
+/* initLinkCellsGpu(SimFlat*, LinkCellGpu*), gpu_utility.c:757-790: geometry + occupancy array of the device link cells (AllocateGpu calls it) */
+void initLinkCellsGpu(LinkCellGpu* boxes, const GpuConfig* cfg);
 /* emptyHaloCellsGpu(SimFlat*), gpu_utility.c: zero the halo cells' occupancy */
 void emptyHaloCellsGpu(SimGpu* sim, comdStream_t stream);
 /* cudaDeviceSynchronize / cudaStreamSynchronize as the host code uses them (eam.c:209, 256) */
@@ -309,6 +311,22 @@ void neighborListForceRebuildGpu(SimGpu* sim);
 void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag);
 /* pairlists (-L) stay out of scope: always "rebuild" */
 int  pairlistUpdateRequiredGpu(SimGpu* sim);
+/* gpu_types.h:38-45 / gpu_kernels.h:71,92: the reference's gid -> slot hash table for its list mode.  Not needed here (atoms keep
+ * their slots between list builds); the two entry points only keep the counters, so the reference's call sites link and run. */
+typedef struct HashTableGpu { int nMaxEntries, nEntriesPut, nEntriesGet; } HashTableGpu;
+void initHashTableGpu(HashTableGpu* hashTable, int nMaxEntries);
+void emptyHashTableGpu(HashTableGpu* hashTable);
+/* comm.h:40-74 (libmp / GPUDirect-Async, excluded from this build): "not in use" answers, so that the reference's host code takes its
+ * plain send/receive path; comm_init's arguments (MPI_Comm, gpuId) are ignored */
+int  comm_use_comm(void);
+int  comm_use_gdrdma(void);
+int  comm_use_async(void);
+int  comm_use_gpu_comm(void);
+int  comm_select_device(int mpiRank);
+#ifndef __cplusplus
+int  comm_init();                       /* (MPI_Comm comm, int gpuId) at the reference's call site; returns 0 */
+#endif
+void comm_finalize(void);
 /* Between list builds the halo copies keep their slots and only their positions are refreshed: gather r (+ the periodic shift of
  * the face) of the listed cells, in list order, into gpu_buf (3 real_t per atom); scatter them into the receive cells.  The
  * reference re-sends whole atoms and finds their slots through a gid hash table (haloExchange.c:1622-1700, hashTable.c). */
