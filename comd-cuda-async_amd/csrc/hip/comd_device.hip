@@ -703,14 +703,31 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
       NlSlabView sv; sv.list = n->list16; sv.count = n->nNeighbors; sv.rows = n->slabRows;
       HIP_CHECK(hipMemsetAsync(n->stats, 0, 2 * sizeof(int), st));
       if (n->slabFormat == 2) {
-         // a wave stages at most `stencilCap` atoms of a 27-cell stencil: 27 full cells, or what 36 KB of LDS per wave hold
-         int stencilCap = 27 * sim->maxAtoms; if (stencilCap > 1536) stencilCap = 1536;
-         const size_t lds = (size_t)EAM_NL_WAVES * (3 * (size_t)stencilCap + 32) * sizeof(double);
-         static size_t attrSet = 0;
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)BuildNeighborListCell16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-         hipLaunchKernelGGL(BuildNeighborListCell16, dim3(ceilDiv(sim->boxes.nLocalBoxes, EAM_NL_WAVES * 8)), dim3(64 * EAM_NL_WAVES), lds, st,
-                            sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
-                            sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status, stencilCap);
+         // A wave stages a whole 27-cell stencil; the LDS it needs decides how many waves share a CU.  Worst case is 27 full cells
+         // (1188 atoms at 44 slots: one workgroup per CU); what the last build saw (+25 %) is usually 2-3x less.  If a stencil does not
+         // fit, the kernel says so through stats[0] and the build is repeated with the worst-case size.
+         const int worst = 27 * sim->maxAtoms < 1536 ? 27 * sim->maxAtoms : 1536;
+         int stencilCap = n->nBuilds > 0 && n->maxSlabAtoms > 0 ? n->maxSlabAtoms + n->maxSlabAtoms / 4 + 16 : worst;
+         if (stencilCap > worst) stencilCap = worst;
+         for (;;) {
+            const size_t lds = (size_t)EAM_NL_WAVES * (3 * (size_t)stencilCap + 32 + (16 * (size_t)n->slabRows * 2 + 7) / 8) * sizeof(double);
+            static size_t attrSet = 0;
+            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)BuildNeighborListCell16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+            HIP_CHECK(hipMemsetAsync(n->stats, 0, 2 * sizeof(int), st));
+            hipLaunchKernelGGL(BuildNeighborListCell16, dim3(ceilDiv(sim->boxes.nLocalBoxes, EAM_NL_WAVES * 8)), dim3(64 * EAM_NL_WAVES), lds, st,
+                               sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
+                               sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status, stencilCap);
+            LAUNCH_CHECK();
+            int h[2];
+            HIP_CHECK(hipMemcpyAsync(h, n->stats, sizeof h, hipMemcpyDeviceToHost, st));
+            HIP_CHECK(hipStreamSynchronize(st));
+            n->maxSlabAtoms = h[0]; n->maxCellAtoms = h[1] > 0 ? h[1] : 1;
+            if (h[0] <= stencilCap || stencilCap == worst) break;
+            stencilCap = worst;
+         }
+         n->forceRebuildFlag = 0;
+         n->nBuilds++;
+         return;
       } else
       {
          // one workgroup per cell, a thread per slot; the LDS holds a whole group of full cells (<= 9 * 512 atoms = 108 KB)

@@ -402,14 +402,16 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-   double* __restrict__ sp = (double*)ldsRaw + (size_t)wave * (3 * stencilCapacity + 32);
+   const int hitDoubles = (16 * nl.rows * 2 + 7) / 8;        // [16 atoms][rows] 16-bit entries
+   double* __restrict__ sp = (double*)ldsRaw + (size_t)wave * (3 * stencilCapacity + 32 + hitDoubles);
    int* sOff = (int*)(sp + 3 * stencilCapacity);
    int* sBox = sOff + 32;
+   unsigned short* sHit = (unsigned short*)(sBox + 32);
    const int q = lane & 3, ia = lane >> 2;
    const int nWaves = gridDim.x * EAM_NL_WAVES;
    const int gw = blockIdx.x * EAM_NL_WAVES + wave;
    const int per = (nCells + nWaves - 1) / nWaves;
-   bool over = false;
+   bool over = false, tooSmall = false;
    for (int iBox = gw * per; iBox < (gw + 1) * per && iBox < nCells; ++iBox) {
       {
          const int box = lane < 27 ? nbr[(size_t)iBox * 27 + lane] : 0;
@@ -422,7 +424,7 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
       __builtin_amdgcn_wave_barrier();
       const int total = uniform(sOff[27]), ni = uniform(sOff[1]);
       if (lane == 0) { atomicMax(&stats[0], total); atomicMax(&stats[1], ni); }
-      if (total > stencilCapacity) { over = true; continue; }            // reported below; the lists of this cell stay empty
+      if (total > stencilCapacity) { tooSmall = true; continue; }      // the host sees stats[0] > capacity and repeats the build (worst-case capacity: flagged)
       for (int t0 = 0; t0 < total; t0 += 256) {
          double vx[4], vy[4], vz[4];
 #pragma unroll
@@ -460,15 +462,26 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
             }
             const unsigned nib = (unsigned)(__ballot(hit) >> (lane & ~3)) & 0xFu;
             const int k = n + __popc(nib & ((1u << q) - 1u));
-            if (hit && k < nl.rows) row[(size_t)k * cap] = (unsigned short)t;
+            if (hit && k < nl.rows) sHit[ia * nl.rows + k] = (unsigned short)t;      // collected in the LDS first ...
             n += __popc(nib);
          }
          if (n > nl.rows) { over = true; n = nl.rows; }
          if (have && q == 0) nl.count[iSlot] = n;
+         // ... and written out four rows per instruction, 16 atoms x 2 bytes contiguous in each (a store per hit from the loop
+         // above touches 64 different lines per instruction and made the build store-address bound: 4.1 -> 2 ms)
+         __builtin_amdgcn_wave_barrier();
+         int nMax = have ? n : 0;
+#pragma unroll
+         for (int m = 32; m >= 4; m >>= 1) { const int o = __shfl_xor(nMax, m); nMax = o > nMax ? o : nMax; }
+         for (int k0 = 0; k0 < nMax; k0 += 4) {
+            const int k = k0 + q;
+            if (have && k < n) row[(size_t)k * cap] = sHit[ia * nl.rows + k];
+         }
+         __builtin_amdgcn_wave_barrier();
       }
       __builtin_amdgcn_wave_barrier();
    }
-   if (over) atomicOr(&status[3], 2);
+   if (over || (tooSmall && stencilCapacity >= 1536)) atomicOr(&status[3], 2);
 }
 
 // quad sum: every lane of an aligned group of 4 ends with the group's total
