@@ -39,7 +39,7 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6
 FORCE_FLOP = {"lj": 4000 * 8 + 550 * 25, "eam": 2 * (283 * 8 + 42 * 70)}
 # Verlet lists (skin 10 %): ~732 (LJ) / ~57 (EAM) listed neighbours take the place of the stencil candidates
 FORCE_FLOP_NL = {"lj": 732 * 8 + 550 * 25, "eam": 2 * (57 * 8 + 42 * 70)}
-KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs",
+KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs", ("lj", "cta_cell_pairlist"): "LJ_Force_cta_cell",
                ("eam", "thread_atom"): "EAM_Force_thread_atom", ("eam", "cta_cell"): "EAM_Force_cta_cell", ("eam", "thread_atom_nl"): "EAM_Force_nl_lds"}
 
 
@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pot", choices=["lj", "eam"], default="lj")
-    ap.add_argument("--method", choices=["thread_atom", "thread_atom_nl", "cta_cell"], default=None)
+    ap.add_argument("--method", choices=["thread_atom", "thread_atom_nl", "cta_cell", "cta_cell_pairlist"], default=None)
     ap.add_argument("--nx", type=int, default=80, help="unit cells per GPU along each axis")
     ap.add_argument("--async-halo", type=int, default=None, help="-a flag: overlap interior force with the halo exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -132,8 +132,9 @@ def main():
 
     def measure(pot, meth, steps, warmup):
         """One Simulation of `pot`/`meth`: W untimed steps, then exactly K steps between barrier + device syncs."""
+        pairlist = meth == "cta_cell_pairlist"                # the reference's -L: pairlist bits for the CTA-per-cell LJ kernel
         args = ["-x", a.nx * px, "-y", a.nx * py, "-z", a.nx * pz, "-i", px, "-j", py, "-k", pz,
-                "-m", meth, "-a", use_async] + (["-e"] if pot == "eam" else [])
+                "-m", "cta_cell" if pairlist else meth, "-a", use_async] + (["-e"] if pot == "eam" else []) + (["-L"] if pairlist else [])
         sim = pkg.Simulation(args)
 
         def sync_all():
@@ -205,14 +206,14 @@ def main():
     # the other force methods on the same workload (one GPU only): not the headline, reported beside it
     variants = []
     if a.gpus == 1 and not a.no_variants:
-        for pot, meth in (("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("lj", "cta_cell"), ("eam", "cta_cell"), ("eam", "thread_atom_nl"), ("eam", "thread_atom")):
+        for pot, meth in (("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("lj", "cta_cell"), ("lj", "cta_cell_pairlist"), ("eam", "cta_cell"), ("eam", "thread_atom_nl"), ("eam", "thread_atom")):
             if (pot, meth) == (a.pot, method):
                 continue
             v = measure(pot, meth, a.steps, a.warmup)
             variants.append({"workload": f"{pot.upper()} Cu FCC {a.nx}^3, {meth}", "value": v["n_global"] * a.steps / v["elapsed"],
                              "ms_per_step": 1e3 * v["elapsed"] / a.steps, "force_ms_per_step": v["force_ms"] / a.steps,
                              "energy_per_atom_eV": (v["ep"] + v["ek"]) / v["n_global"], "cell_capacity": v["cap"],
-                             **({"neighbor_list_builds_timed": v["nl_builds"]} if meth.endswith("_nl") else {})})
+                             **({"neighbor_list_builds_timed": v["nl_builds"]} if meth.endswith(("_nl", "_pairlist")) else {})})
     if rank == 0:
         if variants:
             out["variants"] = variants

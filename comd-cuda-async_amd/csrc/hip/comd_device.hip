@@ -191,8 +191,15 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
       }
       if (nl->maxNeighbors > 27 * cfg->maxAtoms) nl->maxNeighbors = 27 * cfg->maxAtoms;
       const size_t localSlots = (size_t)cfg->nLocalBoxes * cfg->maxAtoms;
-      nl->slabFormat = !cfg->do_eam && cfg->maxAtoms % 64 == 0 && cfg->maxAtoms <= 512 && !getenv("COMD_NL_GLOBAL");
-      if (cfg->do_eam && cfg->maxAtoms <= 64 && eamCtaTableBytes(1, cfg->nRho, cfg->nPhi) <= 32 * 1024 && !getenv("COMD_NL_GLOBAL")) {
+      nl->slabFormat = !cfg->usePairlist && !cfg->do_eam && cfg->maxAtoms % 64 == 0 && cfg->maxAtoms <= 512 && !getenv("COMD_NL_GLOBAL");
+      if (cfg->usePairlist) {
+         if (cfg->do_eam) { fprintf(stderr, "AllocateGpu: pairlists (-L) are an LJ cta_cell feature\n"); exit(-1); }
+         nl->slabFormat = 3;
+         const int threads = cfg->maxAtoms < 256 ? cfg->maxAtoms : 256;
+         nl->pairlistWaves = (threads + 63) / 64;
+         nl->pairlist = dalloc<unsigned>((size_t)cfg->nLocalBoxes * nl->pairlistWaves * LJ_CTA_SLABS * LJ_PL_WORDS);
+         nl->pairlistBuildId = -1;
+      } else if (cfg->do_eam && cfg->maxAtoms <= 64 && eamCtaTableBytes(1, cfg->nRho, cfg->nPhi) <= 32 * 1024 && !getenv("COMD_NL_GLOBAL")) {
          // EAM with LDS-sized tables: 16-bit entries into the wave's staging of the whole 27-cell stencil
          nl->slabFormat = 2;
          nl->slabRows = nl->maxNeighbors;
@@ -299,7 +306,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->boundary_cells, sim->interior_cells, sim->boundary1_cells,
                     sim->atoms.neighborList.list, sim->atoms.neighborList.nNeighbors, sim->atoms.neighborList.lastR.x,
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
-                    sim->atoms.neighborList.list16, sim->atoms.neighborList.stats };
+                    sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
@@ -398,14 +405,24 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       const size_t lds = ljCtaLdsBytes(sim->maxAtoms);
       static size_t attrSet = 0;
       if (lds > attrSet) {
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
          attrSet = lds;
       }
       // threads = atoms of the fullest cell the host has seen (+16), rounded to whole waves, at most 256; each thread can own two atoms
       int threads = sim->maxAtoms < 256 ? sim->maxAtoms : 256;
-      if (sim->max_atoms_cell > 0 && ((sim->max_atoms_cell + 16 + 63) / 64) * 64 < threads) threads = ((sim->max_atoms_cell + 16 + 63) / 64) * 64;
+      // (not with pairlists: their bits are per wave, so the thread -> atom map must not change between the generating call and the users)
+      if (sim->atoms.neighborList.slabFormat != 3 && sim->max_atoms_cell > 0 && ((sim->max_atoms_cell + 16 + 63) / 64) * 64 < threads)
+         threads = ((sim->max_atoms_cell + 16 + 63) / 64) * 64;
       if (sim->maxAtoms > 2 * threads) { fprintf(stderr, "ljForceGpu: cta_cell supports at most 512 atoms per cell\n"); exit(-1); }
-      hipLaunchKernelGGL(LJ_Force_cta_cell, dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status);
+      NeighborListGpu* n = &sim->atoms.neighborList;
+      LjPairlist pl; pl.words = n->pairlist; pl.wavesMax = n->pairlistWaves;
+      pl.plCut2 = (sim->lj_pot.cutoff + n->skinDistance) * (sim->lj_pot.cutoff + n->skinDistance);
+      if (n->slabFormat != 3)                       hipLaunchKernelGGL(LJ_Force_cta_cell<0>, dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl);
+      else if (n->nBuilds == 0) { fprintf(stderr, "ljForceGpu: -L needs buildNeighborListGpu before the first force call\n"); exit(-1); }
+      else if (n->pairlistBuildId != n->nBuilds)    hipLaunchKernelGGL(LJ_Force_cta_cell<1>, dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl);
+      else                                          hipLaunchKernelGGL(LJ_Force_cta_cell<2>, dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl);
    } else {
       // Measured on MI355X (LJ 80^3): a workgroup of the 3 live waves per cell runs the kernel in 3.94 ms, cap/64 = 4 waves per cell (the
       // tail wave exits at once) in 4.72 ms, single-wave workgroups in 5.64 ms.
@@ -681,7 +698,7 @@ extern "C" void neighborListForceRebuildGpu(SimGpu* sim) { sim->atoms.neighborLi
 extern "C" int neighborListUpdateRequiredGpu(SimGpu* sim)
 {
    NeighborListGpu* n = &sim->atoms.neighborList;
-   if ((!n->list && !n->list16) || n->forceRebuildFlag) return 1;
+   if ((!n->list && !n->list16 && !n->pairlist) || n->forceRebuildFlag) return 1;
    hipStream_t st = S(sim->boundary_stream);
    HIP_CHECK(hipMemsetAsync(n->updateRequired, 0, sizeof(int), st));
    hipLaunchKernelGGL(NeighborListUpdateRequired, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
@@ -695,6 +712,16 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
 {
    (void)method; (void)boundaryFlag;
    NeighborListGpu* n = &sim->atoms.neighborList;
+   if (n->slabFormat == 3) {                   // pairlists: remember where the atoms are; the next force call generates the bits
+      const size_t bytes = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * sizeof(real_t);
+      hipStream_t st = S(sim->boundary_stream);
+      HIP_CHECK(hipMemcpyAsync(n->lastR.x, sim->atoms.r.x, bytes, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(n->lastR.y, sim->atoms.r.y, bytes, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(n->lastR.z, sim->atoms.r.z, bytes, hipMemcpyDeviceToDevice, st));
+      n->forceRebuildFlag = 0;
+      n->nBuilds++;
+      return;
+   }
    if (!n->list && !n->list16) { fprintf(stderr, "buildNeighborListGpu: no lists allocated (GpuConfig.skinDistance == 0)\n"); exit(-1); }
    const real_t cutoff = sim->do_eam ? sim->eam_pot.cutoff : sim->lj_pot.cutoff;
    const real_t rBuild = cutoff + n->skinDistance;
@@ -757,7 +784,8 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
    n->nBuilds++;
 }
 
-extern "C" int pairlistUpdateRequiredGpu(SimGpu*) { return 1; }
+extern "C" int pairlistUpdateRequiredGpu(SimGpu* sim) { return neighborListUpdateRequiredGpu(sim); }
+extern "C" void comdPairlistGenerated(SimGpu* sim) { sim->atoms.neighborList.pairlistBuildId = sim->atoms.neighborList.nBuilds; }
 
 // the reference keeps a gid -> slot hash table for its list mode (hashTable.c); here atoms keep their slots between builds
 extern "C" void initHashTableGpu(HashTableGpu* hashTable, int nMaxEntries) { if (hashTable) { hashTable->nMaxEntries = nMaxEntries; hashTable->nEntriesPut = hashTable->nEntriesGet = 0; } }

@@ -168,14 +168,30 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
 #define LJ_CTA_CELLS     3                 // stencil cells staged per slab: 27 / 3 = 9 slabs, 13 KB of LDS -> the CU fills up with workgroups
 static inline size_t ljCtaLdsBytes(int cap) { return (size_t)3 * (LJ_CTA_CELLS * cap + 8) * 8 + 16 * 4; }   // slab capacity = LJ_CTA_CELLS * cap atoms
 
+// Pairlists (-L; the reference's LJ_Force_cta_cell_pairlist, gpu_lj_cta_cell.h:124-274): one bit per (wave, 8-neighbour trip) says
+// whether ANY atom of the wave is within cutoff + skin of ANY of the trip's eight neighbours.  The bits are generated by the force
+// call that follows a rebuild (PL = 1) and let every later call (PL = 2) skip the dead trips: no LDS reads, no distance tests.
+// They stay valid as long as the Verlet lists would (no atom moved more than skin/2; slots frozen in between).
+// words[((cell * wavesMax + wave) * LJ_CTA_SLABS + slab) * LJ_PL_WORDS + trip/32]
+#define LJ_CTA_SLABS 9
+#define LJ_PL_WORDS  8                     // 256 trips = 2048 staged atoms per slab at most (3 cells of <= 512)
+struct LjPairlist { unsigned* __restrict__ words; int wavesMax; double plCut2; };
+
 // all lanes read the same neighbour pair (LDS broadcast); NA = atoms per thread
-template <int NA>
+template <int NA, int PL>
 __device__ __forceinline__ void slabLoop(const double* sx, const double* sy, const double* sz, int nSlab, const LjArgs& a,
                                          const double (&xi)[2], const double (&yi)[2], const double (&zi)[2],
-                                         double (&fx)[2], double (&fy)[2], double (&fz)[2], double (&e)[2])
+                                         double (&fx)[2], double (&fy)[2], double (&fz)[2], double (&e)[2],
+                                         unsigned* __restrict__ plWords, double plCut2, const bool (&own)[2])
 {
    // eight neighbours per trip: the twelve 16-byte LDS reads are issued together, then evaluated (the slab is padded to a multiple of 8)
+   unsigned word = 0;
    for (int j = 0; j < nSlab; j += 8) {
+      const int trip = j >> 3;
+      if (PL == 2) {
+         if ((trip & 31) == 0) word = (unsigned)__builtin_amdgcn_readfirstlane((int)plWords[trip >> 5]);
+         if (!((word >> (trip & 31)) & 1u)) continue;
+      }
       double2 X[4], Y[4], Z[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
@@ -183,6 +199,7 @@ __device__ __forceinline__ void slabLoop(const double* sx, const double* sy, con
          Y[v] = *reinterpret_cast<const double2*>(sy + j + 2 * v);
          Z[v] = *reinterpret_cast<const double2*>(sz + j + 2 * v);
       }
+      bool near = false;
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
 #pragma unroll
@@ -190,20 +207,27 @@ __device__ __forceinline__ void slabLoop(const double* sx, const double* sy, con
             {
                const double dx = xi[u] - X[v].x, dy = yi[u] - Y[v].x, dz = zi[u] - Z[v].x;
                const double r2 = dx*dx + dy*dy + dz*dz;
+               if (PL == 1) near = near || (own[u] && r2 <= plCut2);
                if (r2 <= a.rc2 && r2 > 0.0) ljPair<true>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
             }
             {
                const double dx = xi[u] - X[v].y, dy = yi[u] - Y[v].y, dz = zi[u] - Z[v].y;
                const double r2 = dx*dx + dy*dy + dz*dz;
+               if (PL == 1) near = near || (own[u] && r2 <= plCut2);
                if (r2 <= a.rc2 && r2 > 0.0) ljPair<true>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
             }
          }
       }
+      if (PL == 1) {
+         if (__ballot(near) != 0ull) word |= 1u << (trip & 31);
+         if ((trip & 31) == 31 || j + 8 >= nSlab) { if ((threadIdx.x & 63) == 0) plWords[trip >> 5] = word; word = 0; }
+      }
    }
 }
 
+template <int PL>
 __global__ __launch_bounds__(256)
-void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status)
+void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    const int slabCap = LJ_CTA_CELLS * a.cap + 8;            // cannot overflow: a cell never holds more than cap atoms
@@ -255,8 +279,9 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status)
       }
       __syncthreads();
 
-      if (!second) slabLoop<1>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e);       // the common case: one atom per thread
-      else         slabLoop<2>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e);
+      unsigned* plWords = PL ? pl.words + (((size_t)iBox * pl.wavesMax + (threadIdx.x >> 6)) * LJ_CTA_SLABS + slab) * LJ_PL_WORDS : nullptr;
+      if (!second) slabLoop<1, PL>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);       // the common case: one atom per thread
+      else         slabLoop<2, PL>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);
    }
    const double fs = 24.0 * a.eps;
 #pragma unroll

@@ -59,5 +59,6 @@ static int ljForce(SimFlat* sim)
    } else {
       ljForceGpu(&sim->gpu, sim->ljInterpolation, sim->gpu.boxes.nLocalBoxes, NULL, sim->pot->cutoff + sim->skinDistance, sim->method);
    }
+   if (sim->usePairlist) comdPairlistGenerated(&sim->gpu);      /* every cell has been through a force call since the last build */
    return 0;
 }

@@ -119,9 +119,13 @@ SimFlat* initSimulationHost(Command cmd)
    }
    else { printf("Error: You have to specify a valid method: -m [thread_atom,thread_atom_nl,cta_cell]\n"); exit(-1); }
    sim->useNL = sim->method == THREAD_ATOM_NL;
-   if (cmd.ljInterpolation || cmd.spline || cmd.usePairlist || cmd.doHilbert) {
-      printf("Error: -I, -P, -L and -H are outside this build's scope (SURVEY.md section 8f).\n"); exit(-1);
+   if (cmd.ljInterpolation || cmd.spline || cmd.doHilbert) {
+      printf("Error: -I, -P and -H are outside this build's scope (SURVEY.md section 8f).\n"); exit(-1);
    }
+   /* -L (CoMD.c:250-255, ljForce.c:141): pairlist bits for the CTA-per-cell LJ kernel; same skin, cells and rebuild rule as the lists */
+   sim->usePairlist = cmd.usePairlist;
+   if (sim->usePairlist && (cmd.doeam || sim->method != CTA_CELL)) { printf("Error: -L applies to LJ with -m cta_cell.\n"); exit(-1); }
+   sim->useNL = sim->useNL || sim->usePairlist;        /* frozen slots between rebuilds, positional halo refresh */
 
    sim->pot = initPotential(cmd.doeam, cmd.potDir, cmd.potName, cmd.potType);
    real_t latticeConstant = cmd.lat;
@@ -183,7 +187,7 @@ SimFlat* initSimulation(Command cmd)
       for (int j = 0; j < 27; ++j) if (nbr[j] != iBox) nbrTable[iBox * 27 + c++] = nbr[j];
    }
    cfg.neighborCells = nbrTable;
-   cfg.skinDistance = sim->skinDistance; cfg.maxNeighbors = cmd.maxNeighbors;
+   cfg.skinDistance = sim->skinDistance; cfg.maxNeighbors = cmd.maxNeighbors; cfg.usePairlist = sim->usePairlist;
    cfg.latticeConstant = cmd.lat < 0.0 ? sim->pot->lat : cmd.lat;
    AllocateGpu(&sim->gpu, &cfg);
    free(nbrTable);

@@ -79,6 +79,10 @@ typedef struct NeighborListGpu {
    int    slabRows;
    int*   stats;                       /* device [2]: {atoms in the largest group, fullest cell} at the last build */
    int    maxSlabAtoms, maxCellAtoms;  /* host copies */
+   /* slabFormat 3: pairlists for LJ cta_cell (-L, gpu_lj_cta_cell.h:124-274): no lists, one bit per (wave, 8-neighbour trip of a slab) */
+   unsigned* pairlist;                 /* device [nLocalBoxes * pairlistWaves * 9 slabs * 8 words] */
+   int    pairlistWaves;               /* waves per cell the bits are laid out for */
+   int    pairlistBuildId;             /* host: nBuilds value the bits were generated for (!= nBuilds: the next force call generates) */
    int    forceRebuildFlag;            /* host: the next neighborListUpdateRequiredGpu answers 1 without looking */
    int    nBuilds;                     /* host: builds since AllocateGpu */
 } NeighborListGpu;
@@ -135,6 +139,7 @@ typedef struct GpuConfig {
    const real_t *phiValues, *rhoValues, *fValues; /* host, n+3 entries each, element 0 = values[-1] */
    const int* neighborCells;                      /* host [nLocalBoxes*27] */
    real_t skinDistance;                           /* > 0: allocate Verlet lists (AllocateGpu's third argument, gpu_utility.c:165) */
+   int    usePairlist;                            /* with skinDistance > 0: pairlist bits for LJ cta_cell instead of lists (CoMD.c:250-268) */
    int    maxNeighbors;                           /* list rows per atom; 0 = derive from cutoff + skin and the FCC density */
    real_t latticeConstant;                        /* for that estimate */
 } GpuConfig;
@@ -185,7 +190,8 @@ void comdCheckStatus(SimGpu* sim, const char* where);
 /* ---- force: gpu_kernels.h:13-24 ------------------------------------------------------------ */
 /* ljForceGpu(SimGpu*, interpolation, num_cells, cells_list, plcutoff, method), gpu_kernels.cu:69-122.
  * cells_list (device) == NULL means cells 0..num_cells-1.  interpolation/plcutoff are accepted for
- * signature parity: interpolation must be 0 (table-LJ is out of scope; non-zero exits), plcutoff is ignored (pairlists likewise).
+ * signature parity: interpolation must be 0 (table-LJ is out of scope; non-zero exits); plcutoff (cutoff + skin) is what the pairlist
+ * bits are generated with when the lists were allocated with GpuConfig.usePairlist and method is CTA_CELL.
  * method THREAD_ATOM_NL / WARP_ATOM_NL walks the Verlet lists (buildNeighborListGpu must have run). */
 void ljForceGpu(SimGpu* sim, int interpolation, int num_cells, int* cells_list, real_t plcutoff, int method);
 void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream);
@@ -309,8 +315,11 @@ void neighborListForceRebuildGpu(SimGpu* sim);
  * local atom (cells must be current: call after the atom exchange), snapshot lastR, clear forceRebuildFlag.
  * boundaryFlag is accepted for signature parity (BOTH = 0 is the only mode the reference enables, timestep.c:59-82). */
 void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag);
-/* pairlists (-L) stay out of scope: always "rebuild" */
+/* pairlistUpdateRequiredGpu(SimGpu*), gpu_kernels.cu:1283-1318: same displacement test as the lists (skin/2 since the last build) */
 int  pairlistUpdateRequiredGpu(SimGpu* sim);
+/* -L: tell the library that a whole force evaluation has run since the last buildNeighborListGpu, i.e. the pairlist bits now exist
+ * for every cell (the first ljForceGpu[Async] calls after a build generate them, interior and boundary launches alike) */
+void comdPairlistGenerated(SimGpu* sim);
 /* gpu_types.h:38-45 / gpu_kernels.h:71,92: the reference's gid -> slot hash table for its list mode.  Not needed here (atoms keep
  * their slots between list builds); the two entry points only keep the counters, so the reference's call sites link and run. */
 typedef struct HashTableGpu { int nMaxEntries, nEntriesPut, nEntriesGet; } HashTableGpu;

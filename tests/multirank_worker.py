@@ -101,8 +101,14 @@ def host_mode(pkg, orc, transport, rank, world, grid, eam, n):
 def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async):
     import torch
     pkg.setup_gpu(0, rank)
+    pairlist = method == "cta_cell_pairlist"
+    if pairlist:
+        method = "cta_cell"
     args = ["-x", n, "-y", n, "-z", n, "-i", grid[0], "-j", grid[1], "-k", grid[2], "-r", 0.1, "-m", method, "-a", use_async] + (["-e"] if eam else [])
-    if method.endswith("_nl") and not eam:
+    if pairlist:
+        args += ["-L", "-S", 0.03]
+        method = "cta_cell_nl"                               # below: run long, expect rebuilds
+    if method.endswith("_nl") and not eam and not pairlist:
         args += ["-S", 0.03]                                 # LJ: the default skin (1.16 A) outlasts the test; 0.35 A does not
     sim = pkg.Simulation(args)
     steps = 40 if method.endswith("_nl") else 12          # list mode: long enough for several list builds and for atoms to change owner

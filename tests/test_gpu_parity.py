@@ -163,6 +163,34 @@ def test_neighbor_list_global_slot_format(gpu, orc, monkeypatch, eam, n, extra):
         assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
 
 
+# ---------------------------------------------------------------- pairlists for LJ cta_cell (-L)
+@pytest.mark.parametrize("n,delta", [(12, 0.0), ((11, 13, 12), 0.2)])
+def test_pairlist_forces_match_oracle(gpu, orc, n, delta):
+    """-L: the first force call generates one bit per (wave, 8-neighbour trip), the second one uses them; both must give the oracle's forces."""
+    with gpu.Simulation(_args(n, 0, delta, "cta_cell", ["-L"])) as sim:
+        o = orc.Oracle(n, eam=0, delta=delta)
+        fo, eo = o.gather(orc.F), o.gather(orc.U)
+        for call in range(2):                                   # 0: generated during initialisation; 1: bits in use
+            if call:
+                sim.compute_force()
+            assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0), call
+            assert np.abs(sim.gather(3) - eo).max() <= TOL["per_atom_energy_abs"], call
+
+
+@pytest.mark.parametrize("skin", [0.1, 0.02])
+def test_pairlist_trace_matches_reference(gpu, skin):
+    ref = S["lj_20"]
+    with gpu.Simulation(_args(20, 0, 0.0, "cta_cell", ["-L", "-S", skin])) as sim:
+        done = 0
+        for step in (10, 50, 100):
+            sim.step(step - done)
+            done = step
+            assert abs(_per_atom(sim)[0] - ref["E_at"][str(step)]) < TOL["energy_per_atom_trace"], step
+        assert (sim.nl_builds > 5) if skin < 0.05 else (sim.nl_builds >= 1)
+        sim.sum_atoms()
+        assert sim.energy()[2] == 4 * 20 ** 3
+
+
 def test_neighbor_list_80_cubed_properties(gpu):
     """Full size (BASELINE configs[1] workload) with lists: recorded step-0 energy, conservation, nothing lost, lists reused."""
     ref = S["lj_80_8ranks"]
