@@ -372,3 +372,33 @@ def test_comd_hip_executable_report(gpu, tmp_path):
     y = open(os.path.join(tmp_path, yamls[0])).read()
     for key in ("Mini-Application Name", "Command Line Parameters:", "nx: 20", "Simulation data:", "Potential data:", "Performance Results:", "AtomUpdateRate:"):
         assert key in y, key
+
+
+# ---------------------------------------------------------------- seeded sweep over box shapes, displacements, methods and overlap modes
+def _sweep_cases():
+    import random
+    rnd = random.Random(7)
+    cases = []
+    for eam, methods, lo, hi in ((0, ["thread_atom", "cta_cell", "thread_atom_nl", "cta_cell -L"], 8, 15), (1, ["thread_atom", "cta_cell", "thread_atom_nl"], 5, 13)):
+        for m in methods:
+            for _ in range(4):
+                n = (rnd.randint(lo, hi), rnd.randint(lo, hi), rnd.randint(lo, hi))
+                cases.append((eam, m, n, rnd.choice([0.0, 0.05, 0.15, 0.3]), rnd.choice([0, 1]), rnd.choice([3, 7])))
+    return cases
+
+
+@pytest.mark.parametrize("eam,method,n,delta,overlap,steps", _sweep_cases())
+def test_seeded_sweep_matches_oracle(gpu, orc, eam, method, n, delta, overlap, steps):
+    """Non-cubic boxes (2 to 4 cells per axis, uneven cell occupancies), displaced lattices, every force method, both overlap modes:
+    forces at step 0 and after a few steps, and the total energy, against the oracle."""
+    m = method.split()
+    with gpu.Simulation(_args(n, eam, delta, m[0], ["-a", overlap] + m[1:])) as sim:
+        o = orc.Oracle(n, eam=eam, delta=delta, cap=max(sim.max_atoms, 64))
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
+        sim.step(steps)
+        o.step(steps)
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= 1e-9 * max(np.abs(fo).max(), 1.0)
+        (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
+        assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
