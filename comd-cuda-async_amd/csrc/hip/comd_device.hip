@@ -644,6 +644,13 @@ extern "C" void compactCellsGpu(char* work_d, int nCells, int* d_cellList, SimGp
    LAUNCH_CHECK();
 }
 
+extern "C" void comdReadDeviceInt2(const int* d_a, const int* d_b, int out[2], comdStream_t stream)
+{
+   HIP_CHECK(hipMemcpyAsync(&out[0], d_a, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+   HIP_CHECK(hipMemcpyAsync(&out[1], d_b, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+   HIP_CHECK(hipStreamSynchronize(S(stream)));
+}
+
 extern "C" int atomMsgCountGpu(SimGpu* sim, const char* msg_d, comdStream_t stream)
 {
    (void)sim;

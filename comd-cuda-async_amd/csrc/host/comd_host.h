@@ -155,6 +155,8 @@ typedef struct HaloExchangeSt {
    int bufCapacity;                       /* bytes per message buffer */
    int (*loadBuffer)(void* parms, void* data, int face, char* buf);       /* returns bytes, or -1: "ask msgBytes when you need it" */
    int (*msgBytes)(void* parms, void* data, int face, char* buf);         /* optional: size of a packed device message (blocks) */
+   /* optional: both messages of an axis phase behind one synchronisation */
+   void (*msgBytes2)(void* parms, void* data, int faceM, char* bufM, int faceP, char* bufP, int out[2]);
    void (*unloadBuffer)(void* parms, void* data, int face, int bufSize, char* buf);
    void (*destroy)(void* parms);
    void* parms;

@@ -102,6 +102,16 @@ static int atomsMsgBytes(void* vparms, void* data, int face, char* buf)
    return COMD_ATOM_MSG_HEADER + n * COMD_ATOM_MSG_BYTES_PER_ATOM;
 }
 
+static void atomsMsgBytes2(void* vparms, void* data, int faceM, char* bufM, int faceP, char* bufP, int out[2])
+{
+   (void)vparms; (void)faceM; (void)faceP;
+   SimFlat* sim = (SimFlat*)data;
+   int n[2];
+   comdReadDeviceInt2((const int*)bufM, (const int*)bufP, n, sim->gpu.boundary_stream);      /* the counts sit in the message headers */
+   out[0] = COMD_ATOM_MSG_HEADER + n[0] * COMD_ATOM_MSG_BYTES_PER_ATOM;
+   out[1] = COMD_ATOM_MSG_HEADER + n[1] * COMD_ATOM_MSG_BYTES_PER_ATOM;
+}
+
 static void unloadAtomsBuffer(void* vparms, void* data, int face, int bufSize, char* buf)
 {
    AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
@@ -129,6 +139,7 @@ HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDev
    hh->bufCapacity = COMD_ATOM_MSG_HEADER + parms->capacityAtoms * COMD_ATOM_MSG_BYTES_PER_ATOM;
    hh->loadBuffer = loadAtomsBuffer;
    hh->msgBytes = atomsMsgBytes;
+   hh->msgBytes2 = atomsMsgBytes2;
    hh->unloadBuffer = unloadAtomsBuffer;
    hh->destroy = destroyAtomsExchange;
    parms->nCells[HALO_X_MINUS] = parms->nCells[HALO_X_PLUS] = 2 * size0;
@@ -169,6 +180,16 @@ static int forceMsgBytes(void* vparms, void* vdata, int face, char* buf)
    return n * (int)sizeof(real_t);
 }
 
+static void forceMsgBytes2(void* vparms, void* vdata, int faceM, char* bufM, int faceP, char* bufP, int out[2])
+{
+   (void)bufM; (void)bufP;
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
+   int n[2];
+   comdReadDeviceInt2(parms->sendOffsetsGpu[faceM] + parms->nCells[faceM], parms->sendOffsetsGpu[faceP] + parms->nCells[faceP], n, s->gpu.boundary_stream);
+   out[0] = n[0] * (int)sizeof(real_t); out[1] = n[1] * (int)sizeof(real_t);
+}
+
 static void unloadForceBuffer(void* vparms, void* vdata, int face, int bufSize, char* buf)
 {
    ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
@@ -199,6 +220,7 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
    hh->bufCapacity = parms->capacityAtoms * (int)sizeof(real_t);
    hh->loadBuffer = loadForceBuffer;
    hh->msgBytes = forceMsgBytes;
+   hh->msgBytes2 = forceMsgBytes2;
    hh->unloadBuffer = unloadForceBuffer;
    hh->destroy = destroyForceExchange;
    parms->nCells[HALO_X_MINUS] = parms->nCells[HALO_X_PLUS] = size0;
@@ -351,6 +373,11 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
       hh->unloadBuffer(hh->parms, data, faceM, nSendP, hh->sendBufP);
       hh->unloadBuffer(hh->parms, data, faceP, nSendM, hh->sendBufM);
       return;
+   }
+   if (nSendM < 0 && nSendP < 0 && hh->msgBytes2) {
+      int n[2];
+      hh->msgBytes2(hh->parms, data, faceM, hh->sendBufM, faceP, hh->sendBufP, n);
+      nSendM = n[0]; nSendP = n[1];
    }
    if (nSendM < 0 && hh->msgBytes) nSendM = hh->msgBytes(hh->parms, data, faceM, hh->sendBufM);
    if (nSendP < 0 && hh->msgBytes) nSendP = hh->msgBytes(hh->parms, data, faceP, hh->sendBufP);

@@ -272,6 +272,8 @@ void scanCellListsGpu(SimGpu* sim, int nLists, int** d_cellLists, const int* nCe
 void comdForceScansReady(int on);
 /* blocking read of one device int (message counts for the multi-rank transport) */
 int  comdReadDeviceInt(const int* d_ptr, comdStream_t stream);
+/* two device ints behind ONE stream synchronisation (the two message counts of an axis phase) */
+void comdReadDeviceInt2(const int* d_a, const int* d_b, int out[2], comdStream_t stream);
 
 
 /* ---- inter-rank transport: replaces comm.h:40-74 (libmp/GPUDirect-Async) and parallel.h (MPI) --------------
