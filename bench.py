@@ -112,6 +112,7 @@ def main():
     # One GPU can rehearse the multi-GPU code path: COMD_LOOPBACK_TRANSPORT=1 sends every halo message and reduction of the
     # single rank through RCCL (to itself), with the same library load order and rendezvous as a torch.distributed.run launch.
     loopback = world == 1 and os.environ.get("COMD_LOOPBACK_TRANSPORT", "0") not in ("", "0")
+    transport_name = None
     dist = None
     if world > 1 or loopback:
         import torch.distributed as dist                    # torch first: its bundled HIP/RCCL runtime is the one both sides share
@@ -125,8 +126,20 @@ def main():
     if dist is not None:
         ids = [pkg.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
-        transport = pkg.rccl_transport(rank, world, ids[0])
-        pkg.init_parallel(rank, world, transport)
+        import torch
+        try:
+            transport = pkg.rccl_transport(rank, world, ids[0])
+            ok = 1
+        except RuntimeError:
+            ok = 0
+        flag = torch.tensor([ok])
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks agree on the transport
+        if int(flag[0]) == 1:
+            pkg.init_parallel(rank, world, transport)
+        else:                                                # no RCCL communicator: host-staged messages over gloo, and say so
+            transport_name = "gloo-host-staged (RCCL communicator could not be formed)"
+            gloo = pkg.GlooTransport(dist)
+            pkg.init_parallel(rank, world, gloo.struct)
     else:
         pkg.init_parallel(0, 1, None)
 
@@ -186,7 +199,7 @@ def main():
             "config": {"workload": f"{a.pot.upper()} Cu FCC {a.nx}^3 unit cells per GPU ({int(n_local)} atoms/GPU, {n_global} total), "
                                    f"{method} kernel, fp64, T=600 K, dt=1 fs",
                        "decomposition": f"{px}x{py}x{pz}", "halo_overlap": bool(use_async), "cell_capacity": m["cap"],
-                       **({"transport": "rccl-loopback"} if loopback else {})},
+                       **({"transport": transport_name or ("rccl-loopback" if loopback else "rccl")} if a.gpus > 1 or loopback else {})},
             "per_gpu_value": value / a.gpus,
             "energy_per_atom_eV": (ep + ek) / n_global,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -115,7 +115,10 @@ extern "C" int comdCommInitRank(const char* id128, int rank, int nRanks, CommTra
    g_rank = rank; g_nRanks = nRanks;
    ncclUniqueId id;
    memcpy(&id, id128, sizeof id);
-   NCCLC(ncclCommInitRank(&g_comm, nRanks, id, rank));
+   {  // a communicator that cannot be formed is reported, not fatal: the caller may fall back to another transport
+      ncclResult_t r = ncclCommInitRank(&g_comm, nRanks, id, rank);
+      if (r != ncclSuccess) { fprintf(stderr, "Rank %d: ncclCommInitRank failed: %s\n", rank, ncclGetErrorString(r)); g_comm = nullptr; return -1; }
+   }
    HIPC(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
    HIPC(hipMalloc((void**)&g_dSizes, 4 * sizeof(int)));
    HIPC(hipHostMalloc((void**)&g_hSizes, 4 * sizeof(int), hipHostMallocDefault));
