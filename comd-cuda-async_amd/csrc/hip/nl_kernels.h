@@ -412,6 +412,7 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
    const int gw = blockIdx.x * EAM_NL_WAVES + wave;
    const int per = (nCells + nWaves - 1) / nWaves;
    bool over = false, tooSmall = false;
+   int maxTotal = 0, maxNi = 0;
    for (int iBox = gw * per; iBox < (gw + 1) * per && iBox < nCells; ++iBox) {
       {
          const int box = lane < 27 ? nbr[(size_t)iBox * 27 + lane] : 0;
@@ -423,7 +424,7 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
       }
       __builtin_amdgcn_wave_barrier();
       const int total = uniform(sOff[27]), ni = uniform(sOff[1]);
-      if (lane == 0) { atomicMax(&stats[0], total); atomicMax(&stats[1], ni); }
+      maxTotal = total > maxTotal ? total : maxTotal; maxNi = ni > maxNi ? ni : maxNi;      // one atomic per wave at the end, not per cell
       if (total > stencilCapacity) { tooSmall = true; continue; }      // the host sees stats[0] > capacity and repeats the build (worst-case capacity: flagged)
       for (int t0 = 0; t0 < total; t0 += 256) {
          double vx[4], vy[4], vz[4];
@@ -453,17 +454,22 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
          if (have && q == 0) { lastX[iSlot] = xi; lastY[iSlot] = yi; lastZ[iSlot] = zi; }
          unsigned short* __restrict__ row = nl.list + ((size_t)iBox * nl.rows) * cap + ii;
          int n = 0;                                          // hits of atom i so far (the same in its four lanes)
-         for (int t0 = 0; t0 < total; t0 += 4) {             // four records per trip, one per lane of the quad; rows keep record order
-            const int t = t0 + q;
-            bool hit = false;
-            if (have && t < total) {
-               const double dx = xi - sp[3 * t], dy = yi - sp[3 * t + 1], dz = zi - sp[3 * t + 2];
-               hit = dx*dx + dy*dy + dz*dz <= rBuild2 && t != i;
+         for (int t0 = 0; t0 < total; t0 += 16) {            // 16 records per trip, four per lane of the quad; rows keep record order
+            bool hit[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {                     // the four distance tests are independent: 12 LDS reads in flight
+               const int t = t0 + 4 * u + q;
+               const int tt = t < total ? t : 0;
+               const double dx = xi - sp[3 * tt], dy = yi - sp[3 * tt + 1], dz = zi - sp[3 * tt + 2];
+               hit[u] = have && t < total && dx*dx + dy*dy + dz*dz <= rBuild2 && t != i;
             }
-            const unsigned nib = (unsigned)(__ballot(hit) >> (lane & ~3)) & 0xFu;
-            const int k = n + __popc(nib & ((1u << q) - 1u));
-            if (hit && k < nl.rows) sHit[ia * nl.rows + k] = (unsigned short)t;      // collected in the LDS first ...
-            n += __popc(nib);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+               const unsigned nib = (unsigned)(__ballot(hit[u]) >> (lane & ~3)) & 0xFu;
+               const int k = n + __popc(nib & ((1u << q) - 1u));
+               if (hit[u] && k < nl.rows) sHit[ia * nl.rows + k] = (unsigned short)(t0 + 4 * u + q);      // collected in the LDS first ...
+               n += __popc(nib);
+            }
          }
          if (n > nl.rows) { over = true; n = nl.rows; }
          if (have && q == 0) nl.count[iSlot] = n;
@@ -481,6 +487,7 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
       }
       __builtin_amdgcn_wave_barrier();
    }
+   if (lane == 0) { atomicMax(&stats[0], maxTotal); atomicMax(&stats[1], maxNi); }
    if (over || (tooSmall && stencilCapacity >= 1536)) atomicOr(&status[3], 2);
 }
 
