@@ -402,3 +402,18 @@ def test_seeded_sweep_matches_oracle(gpu, orc, eam, method, n, delta, overlap, s
         assert np.abs(sim.gather(2) - fo).max() <= 1e-9 * max(np.abs(fo).max(), 1.0)
         (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
         assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
+
+
+# ---------------------------------------------------------------- determinism
+@pytest.mark.parametrize("eam,n,method", [(0, 14, "thread_atom"), (0, 14, "cta_cell"), (0, 14, "thread_atom_nl"), (1, 12, "cta_cell"), (1, 12, "thread_atom_nl")])
+def test_runs_are_bit_reproducible(gpu, eam, n, method):
+    """No floating-point atomics anywhere on the path and every cell in gid order: two runs of the same input agree to the last bit
+    (the reference's energy reduction and its unsorted halo cells make its runs differ, gpu_reduce.h:32-98)."""
+    out = []
+    for _ in range(2):
+        with gpu.Simulation(_args(n, eam, 0.1, method, ["-a", 1])) as sim:
+            sim.step(25)
+            out.append((sim.gather(0), sim.gather(1), sim.gather(2), sim.energy()))
+    for a, b in zip(out[0][:3], out[1][:3]):
+        assert np.array_equal(a, b)
+    assert out[0][3] == out[1][3]
