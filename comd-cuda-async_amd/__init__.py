@@ -103,6 +103,8 @@ def lib_host():
         lib.comdHostAtoms.argtypes = [vp]
         lib.comdHostAtoms.restype = ctypes.POINTER(HostAtoms)
         lib.comdGridInfo.argtypes = [vp, c_int_p]
+        lib.comdEamTable.argtypes = [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.c_void_p]
+        lib.comdEamTable.restype = ctypes.c_int
         lib.comdNeighborListBuilds.argtypes = [vp]
         lib.comdNeighborListBuilds.restype = ctypes.c_int
         lib.comdSimBoxFromTuple.argtypes = [vp, ctypes.c_int, ctypes.c_int, ctypes.c_int]
@@ -193,6 +195,15 @@ class Simulation:
 
     def compute_force(self):
         self.lib.computeForce(self.ptr)
+
+    def eam_table(self, which):
+        """(x0, invDx, padded samples) of the EAM table 0 phi / 1 rho / 2 F as the host hands it to AllocateGpu."""
+        import numpy as np
+        x0, inv = ctypes.c_double(), ctypes.c_double()
+        n = self.lib.comdEamTable(self.ptr, which, ctypes.byref(x0), ctypes.byref(inv), None)
+        v = np.empty(n + 3)
+        self.lib.comdEamTable(self.ptr, which, ctypes.byref(x0), ctypes.byref(inv), v.ctypes.data_as(ctypes.c_void_p))
+        return x0.value, inv.value, v
 
     @property
     def nl_builds(self):

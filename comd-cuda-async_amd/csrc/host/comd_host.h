@@ -272,6 +272,7 @@ void     comdNeighborRanks(SimFlat* s, int nbr[6], int coord[3]);
 void     comdHaloExchangeHost(SimFlat* s, int (*load)(void*, void*, int, char*), void (*unload)(void*, void*, int, int, char*));
 void     comdFaceShift(SimFlat* s, int face, double out[3]);
 int      comdPutAtomInBox(SimFlat* s, int gid, int type, const double r[3], const double p[3]);
+int      comdEamTable(SimFlat* s, int which, double* x0, double* invDx, double* values);   /* 0 phi, 1 rho, 2 F; n + 3 padded samples */
 int      comdNeighborListBuilds(SimFlat* s);              /* Verlet-list builds so far (*_nl methods) */
 void     comdGridInfo(SimFlat* s, int out[6]);            /* gridSize[3], nLocalBoxes, nTotalBoxes, maxAtoms */
 int      comdMain(int argc, char** argv);                /* the reference's main(): CoMD.c:86-187 */

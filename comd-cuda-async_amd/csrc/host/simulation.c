@@ -394,6 +394,17 @@ const HostAtoms* comdHostAtoms(SimFlat* s) { return &s->atoms->h; }
 
 int comdNeighborListBuilds(SimFlat* s) { return s->nlBuilds; }
 
+/* EAM table `which` (0 phi, 1 rho, 2 F) as the device receives it: n, x0, invDx and the n + 3 padded samples (values[0] = leading pad) */
+int comdEamTable(SimFlat* s, int which, double* x0, double* invDx, double* values)
+{
+   if (!s->cmdDoeam) return 0;
+   EamPotential* e = (EamPotential*)s->pot;
+   InterpolationObject* t = which == 0 ? e->phi : which == 1 ? e->rho : e->f;
+   *x0 = t->x0; *invDx = t->invDx;
+   if (values) for (int i = -1; i <= t->n + 1; ++i) values[i + 1] = t->values[i];
+   return t->n;
+}
+
 void comdGridInfo(SimFlat* s, int out[6])
 {
    for (int a = 0; a < 3; ++a) out[a] = s->boxes->gridSize[a];

@@ -148,3 +148,22 @@ def test_lj_thread_atom_keeps_its_scalar_load_stream(tmp_path):
     assert len(kernels) == 2
     for name, body in kernels:
         assert body.count("s_load_dwordx16") >= 3, name
+
+
+@pytest.mark.parametrize("extra,pot_name", [((), "Cu_u6.eam"), (("-t", "setfl", "-p", "Cu01.eam.alloy"), "Cu01.eam.alloy")])
+def test_eam_tables_of_host_and_oracle_agree(pkg, orc, extra, pot_name):
+    """funcfl (eam.c:802-872) and setfl (eam.c:680-757) readers: grid, padding and every sample of phi, rho and F, bit for bit."""
+    import ctypes
+    sim = pkg.Simulation(["-x", 6, "-y", 6, "-z", 6, "-e"] + list(extra), host_only=True)
+    o = orc.Oracle(6, eam=1, pot_name=pot_name)
+    L = orc.lib()
+    for which in range(3):
+        x0, inv, v = sim.eam_table(which)
+        n, ox0, oinv = ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+        assert L.oracle_eam_table(o.ptr, which, ctypes.byref(n), ctypes.byref(ox0), ctypes.byref(oinv), None) == 0
+        ov = np.empty(n.value + 3)
+        L.oracle_eam_table(o.ptr, which, ctypes.byref(n), ctypes.byref(ox0), ctypes.byref(oinv), ov.ctypes.data_as(ctypes.c_void_p))
+        assert (n.value + 3, x0, inv) == (len(v), ox0.value, oinv.value)
+        assert np.array_equal(v, ov)
+        assert v[0] == v[1] and v[-1] == v[-2] == v[-3]      # eam.c:510-513 padding
+    sim.close()
