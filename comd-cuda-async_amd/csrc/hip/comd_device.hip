@@ -405,9 +405,12 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       const size_t lds = ljCtaLdsBytes(sim->maxAtoms);
       static size_t attrSet = 0;
       if (lds > attrSet) {
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
          attrSet = lds;
       }
       // threads = atoms of the fullest cell the host has seen (+16), rounded to whole waves, at most 256; each thread can own two atoms
@@ -419,10 +422,13 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       NeighborListGpu* n = &sim->atoms.neighborList;
       LjPairlist pl; pl.words = n->pairlist; pl.wavesMax = n->pairlistWaves;
       pl.plCut2 = (sim->lj_pot.cutoff + n->skinDistance) * (sim->lj_pot.cutoff + n->skinDistance);
-      if (n->slabFormat != 3)                       hipLaunchKernelGGL(LJ_Force_cta_cell<0>, dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl);
+#define LAUNCH_CTA(PLV) do { if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_cta_cell<PLV, true>), dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl); \
+                            else              hipLaunchKernelGGL((LJ_Force_cta_cell<PLV, false>), dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl); } while (0)
+      if (n->slabFormat != 3)                    LAUNCH_CTA(0);
       else if (n->nBuilds == 0) { fprintf(stderr, "ljForceGpu: -L needs buildNeighborListGpu before the first force call\n"); exit(-1); }
-      else if (n->pairlistBuildId != n->nBuilds)    hipLaunchKernelGGL(LJ_Force_cta_cell<1>, dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl);
-      else                                          hipLaunchKernelGGL(LJ_Force_cta_cell<2>, dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl);
+      else if (n->pairlistBuildId != n->nBuilds) LAUNCH_CTA(1);
+      else                                       LAUNCH_CTA(2);
+#undef LAUNCH_CTA
    } else {
       // Measured on MI355X (LJ 80^3): a workgroup of the 3 live waves per cell runs the kernel in 3.94 ms, cap/64 = 4 waves per cell (the
       // tail wave exits at once) in 4.72 ms, single-wave workgroups in 5.64 ms.

@@ -178,7 +178,7 @@ static inline size_t ljCtaLdsBytes(int cap) { return (size_t)3 * (LJ_CTA_CELLS *
 struct LjPairlist { unsigned* __restrict__ words; int wavesMax; double plCut2; };
 
 // all lanes read the same neighbour pair (LDS broadcast); NA = atoms per thread
-template <int NA, int PL>
+template <int NA, int PL, bool SELF, bool ENERGY>
 __device__ __forceinline__ void slabLoop(const double* sx, const double* sy, const double* sz, int nSlab, const LjArgs& a,
                                          const double (&xi)[2], const double (&yi)[2], const double (&zi)[2],
                                          double (&fx)[2], double (&fy)[2], double (&fz)[2], double (&e)[2],
@@ -208,13 +208,13 @@ __device__ __forceinline__ void slabLoop(const double* sx, const double* sy, con
                const double dx = xi[u] - X[v].x, dy = yi[u] - Y[v].x, dz = zi[u] - Z[v].x;
                const double r2 = dx*dx + dy*dy + dz*dz;
                if (PL == 1) near = near || (own[u] && r2 <= plCut2);
-               if (r2 <= a.rc2 && r2 > 0.0) ljPair<true>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
+               if (SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2)) ljPair<ENERGY>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
             }
             {
                const double dx = xi[u] - X[v].y, dy = yi[u] - Y[v].y, dz = zi[u] - Z[v].y;
                const double r2 = dx*dx + dy*dy + dz*dz;
                if (PL == 1) near = near || (own[u] && r2 <= plCut2);
-               if (r2 <= a.rc2 && r2 > 0.0) ljPair<true>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
+               if (SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2)) ljPair<ENERGY>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
             }
          }
       }
@@ -225,7 +225,8 @@ __device__ __forceinline__ void slabLoop(const double* sx, const double* sy, con
    }
 }
 
-template <int PL>
+// ENERGY = false drops the energy arithmetic (comdSetEnergyNeeded); only the first slab holds the cell itself and needs the r2 > 0 guard
+template <int PL, bool ENERGY>
 __global__ __launch_bounds__(256)
 void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
 {
@@ -280,8 +281,13 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
       __syncthreads();
 
       unsigned* plWords = PL ? pl.words + (((size_t)iBox * pl.wavesMax + (threadIdx.x >> 6)) * LJ_CTA_SLABS + slab) * LJ_PL_WORDS : nullptr;
-      if (!second) slabLoop<1, PL>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);       // the common case: one atom per thread
-      else         slabLoop<2, PL>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);
+      if (slab == 0) {                                       // the self-first neighbour table puts the cell itself into slab 0
+         if (!second) slabLoop<1, PL, true, ENERGY>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);
+         else         slabLoop<2, PL, true, ENERGY>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);
+      } else {
+         if (!second) slabLoop<1, PL, false, ENERGY>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);       // the common case: one atom per thread
+         else         slabLoop<2, PL, false, ENERGY>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);
+      }
    }
    const double fs = 24.0 * a.eps;
 #pragma unroll
@@ -289,6 +295,6 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
       if (own[u]) {
          const size_t io = (size_t)iBox * a.cap + threadIdx.x + u * nThreads;
          a.fx[io] = fx[u] * fs; a.fy[io] = fy[u] * fs; a.fz[io] = fz[u] * fs;
-         a.e[io] = e[u] * 2.0 * a.eps;
+         if (ENERGY) a.e[io] = e[u] * 2.0 * a.eps;
       }
 }
