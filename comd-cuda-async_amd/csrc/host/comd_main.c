@@ -12,7 +12,9 @@ int main(int argc, char** argv)
    CommTransport t; memset(&t, 0, sizeof t);
    int rank = 0, nRanks = 1, localRank = 0;
    const char* ws = getenv("WORLD_SIZE");
-   int multi = ws && atoi(ws) > 1;
+   const char* lb = getenv("COMD_LOOPBACK_TRANSPORT");
+   /* WORLD_SIZE=1 with COMD_LOOPBACK_TRANSPORT=1: the one rank still bootstraps RCCL and talks to itself through it */
+   int multi = ws && (atoi(ws) > 1 || (atoi(ws) == 1 && lb && atoi(lb) != 0));
    if (multi) {
       localRank = getenv("LOCAL_RANK") ? atoi(getenv("LOCAL_RANK")) : 0;
       SetupGpu(localRank, getenv("RANK") ? atoi(getenv("RANK")) : 0, 0);

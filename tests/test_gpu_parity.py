@@ -343,14 +343,19 @@ def test_full_size_properties(gpu, eam, method, steps):
 
 
 # ---------------------------------------------------------------- the executable: CLI, stdout table, validation block, YAML
-def test_comd_hip_executable_report(gpu, tmp_path):
+@pytest.mark.parametrize("launcher_env", [False, True])
+def test_comd_hip_executable_report(gpu, tmp_path, launcher_env):
     """`comd-hip` is the reference's CoMD binary for this path: same flags, same table (CoMD.c:478-493), same validation block
-    (CoMD.c:421-438), a YAML side file (yamlOutput.c:45-67).  LJ 20^3, 20 steps: the rows must carry the reference's energies."""
+    (CoMD.c:421-438), a YAML side file (yamlOutput.c:45-67).  LJ 20^3, 20 steps: the rows must carry the reference's energies.
+    launcher_env: started the way a multi-process launcher would (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT), one rank, loopback:
+    the RCCL id travels through the rendezvous file and every halo message through ncclSend/ncclRecv."""
     import re
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "comd-cuda-async_amd", "csrc", "comd-hip")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    if launcher_env:
+        env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_PORT="29611", COMD_LOOPBACK_TRANSPORT="1", COMD_RDZV_DIR=str(tmp_path))
     proc = subprocess.run([exe, "-x", "20", "-y", "20", "-z", "20", "-N", "20", "-n", "10", "-d", os.path.join(root, "pots")],
                           capture_output=True, text=True, cwd=tmp_path, env=env, timeout=300)
     assert proc.returncode == 0, proc.stderr[-2000:]
