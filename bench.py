@@ -58,6 +58,20 @@ def parse():
     return ap.parse_args()
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner to stdout when a communicator is created; stdout must carry the JSON line only."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def cpu_baseline(pot, seconds):
     """Time the oracle on this host: 20^3 cells of the same lattice/potential (BASELINE configs[0] for LJ)."""
     orc = ge.load_oracle()
@@ -118,17 +132,20 @@ def main():
         import torch.distributed as dist                    # torch first: its bundled HIP/RCCL runtime is the one both sides share
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; halo data moves over RCCL
+        with stdout_to_stderr():                           # gloo announces its peers on stdout
+            dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; halo data moves over RCCL
     pkg = ge.load_package()
     if "COMD_FORCE_DEVICE" in os.environ:               # debugging aid: several ranks on one GPU
         local_rank = int(os.environ["COMD_FORCE_DEVICE"])
     pkg.setup_gpu(local_rank, rank, verbose=False)         # stdout carries exactly one line: the JSON
     if dist is not None:
-        ids = [pkg.rccl_unique_id() if rank == 0 else None]
+        with stdout_to_stderr():
+            ids = [pkg.rccl_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(ids, src=0)
         import torch
         try:
-            transport = pkg.rccl_transport(rank, world, ids[0])
+            with stdout_to_stderr():
+                transport = pkg.rccl_transport(rank, world, ids[0])
             ok = 1
         except RuntimeError:
             ok = 0
