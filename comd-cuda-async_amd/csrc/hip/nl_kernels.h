@@ -4,11 +4,15 @@
 // :1486-2029 (buildNeighborListGpu and the *_nl force kernels) and its gid hash table (hashTable.c): lists hold every
 // atom within cutoff + skin, link cells are sized cutoff + skin, and the lists stay valid until some atom has moved
 // more than skin/2 since the build.  Between builds no atom changes its slot (no re-binning, CoMD.c:257-268 /
-// timestep.c:278-352), so here a list entry is simply the neighbour's global slot and the halo copies are refreshed
-// in place by a positional exchange (the slot-ordered path of the dF/drho exchange) -- no hash table.
+// timestep.c:278-352), so here a list entry names a slot, never a gid, and the halo copies are refreshed in place by a
+// positional exchange (the slot-ordered path of the dF/drho exchange) -- no hash table.
 //
-// Layout: list[(cell * maxNbr + k) * cap + i] = slot of the k-th neighbour of atom i of `cell`: a wave reading entry k
-// of its 64 atoms reads 256 consecutive bytes.
+// Three list formats (NeighborListGpu.slabFormat), all row-major over the atoms of a cell so that a wave reads row k of its
+// atoms as one line:
+//   1  LJ:  16-bit offsets into the LDS staging of one group of 9 stencil cells   (LJ_Force_nl_slabs, second half of this file)
+//   2  EAM: 16-bit record numbers in a wave's LDS staging of the whole 27-cell stencil (EAM_Force_nl_lds, end of this file)
+//   0  plain: list[(cell * maxNbr + k) * cap + i] = global slot of the k-th neighbour, gathered from global memory -- the fallback
+//      for cells of more than 512 slots and for EAM tables that do not fit the LDS (setfl); kernels directly below.
 #pragma once
 #include "device_common.h"
 #include "lj_kernels.h"
