@@ -82,8 +82,8 @@ def main():
                f"(`profiles/r01_80_*_nl_kernel_stats.csv`) LJ builds {builds['lj'][0]} time(s) ({builds['lj'][1]:.1f} ms each) and EAM {builds['eam'][0]} times ({builds['eam'][1]:.1f} ms each), "
                f"i.e. +{builds['lj'][0] * builds['lj'][1] / 110:.2f} / +{builds['eam'][0] * builds['eam'][1] / 110:.2f} ms per step.  "
                "FLOP model for the list kernels: 732 (LJ) / 57 (EAM) listed pairs x 8 + 550 / 42 evaluated pairs x 25 / 70.\n")
-    out.append("LJ 256^3 (67,108,864 atoms, the BASELINE target line), `bench.py --nx 256 --steps 3 --warmup 1`, thread_atom: 126.3 ms/step = 531 M atom-updates/s "
-               "(measured mid-round; that kernel has not changed since).  The list method does not fit 256^3 on one GPU (its lists alone would be ~390 GB).\n")
+    out.append("LJ 256^3 (67,108,864 atoms, the BASELINE target line), `bench.py --nx 256 --steps 3 --warmup 1`, thread_atom: 123.4 ms/step = 544 M atom-updates/s "
+               "(`profiles/r01_bench_lj256.json`).  The list method does not fit 256^3 on one GPU (its lists alone would be ~390 GB).\n")
     out.append("comd-hip stdout of the reference's 20^3 cases (`profiles/r01_comd_hip_*_stdout.txt`): LJ E(100) = -1.329021332207, EAM E(100) = -3.460530084715 with "
                "thread_atom, cta_cell, cta_cell -L AND thread_atom_nl -- the reference CPU values to the last printed digit; setfl (Mishin Cu01) step-0 U = -3.539999969172 "
                "(CoMD.c:899: -3.539999969176).\n")
