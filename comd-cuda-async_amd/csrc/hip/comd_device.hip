@@ -142,6 +142,13 @@ extern "C" void initLinkCellsGpu(LinkCellGpu* b, const GpuConfig* cfg)
       b->invBoxSize[a] = 1.0 / cfg->boxSize[a];
    }
    b->nAtoms = dalloc<int>(cfg->nTotalBoxes);
+   b->boxIDLookUp = b->boxIDLookUpReverse = nullptr;
+   if (cfg->boxIDLookUp && cfg->boxIDLookUpReverse) {     // gpu_utility.c:594-595
+      b->boxIDLookUp = dalloc<int>(cfg->nLocalBoxes, false);
+      b->boxIDLookUpReverse = dalloc<int>(cfg->nLocalBoxes, false);
+      HIP_CHECK(hipMemcpy(b->boxIDLookUp, cfg->boxIDLookUp, (size_t)cfg->nLocalBoxes * sizeof(int), hipMemcpyHostToDevice));
+      HIP_CHECK(hipMemcpy(b->boxIDLookUpReverse, cfg->boxIDLookUpReverse, (size_t)cfg->nLocalBoxes * sizeof(int), hipMemcpyHostToDevice));
+   }
 }
 
 extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
@@ -306,7 +313,8 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->boundary_cells, sim->interior_cells, sim->boundary1_cells,
                     sim->atoms.neighborList.list, sim->atoms.neighborList.nNeighbors, sim->atoms.neighborList.lastR.x,
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
-                    sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist };
+                    sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
+                    sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));

@@ -157,5 +157,6 @@ __device__ __forceinline__ CellGeom makeGeom(const LinkCellGpu& b)
    CellGeom c;
    for (int a = 0; a < 3; ++a) { c.g[a] = b.gridSize[a]; c.lmin[a] = b.localMin[a]; c.lmax[a] = b.localMax[a]; c.inv[a] = b.invBoxSize[a]; }
    c.nLocal = b.nLocalBoxes; c.nTotal = b.nTotalBoxes;
+   c.lookup = b.boxIDLookUp; c.reverse = b.boxIDLookUpReverse;
    return c;
 }

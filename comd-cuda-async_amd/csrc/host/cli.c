@@ -52,7 +52,7 @@ Command parseCommandLine(int argc, char** argv)
       { "lat",          'l', 1, 'd', &cmd.lat,            0, "lattice parameter (Angstroms)" },
       { "temp",         'T', 1, 'd', &cmd.temperature,    0, "initial temperature (K)" },
       { "delta",        'r', 1, 'd', &cmd.initialDelta,   0, "initial delta (Angstroms)" },
-      { "hilbert",      'H', 0, 'i', &cmd.doHilbert,      0, "space-filling curve for the traversal of cells (not supported)" },
+      { "hilbert",      'H', 0, 'i', &cmd.doHilbert,      0, "space-filling (Hilbert) curve for the numbering of the link cells" },
       { "skinDistance", 'S', 1, 'd', &cmd.relativeSkinDistance, 0, "skinDistance (relative to cutoff (default: 0.1))" },
       { "method",       'm', 1, 's', cmd.method,  sizeof cmd.method,  "thread_atom,thread_atom_nl,cta_cell (warp_atom[_nl] run as thread_atom[_nl])" },
       { "gpuAsync",     'a', 1, 'i', &cmd.gpuAsync,       0, "communicaton hiding optimization using streams" },

@@ -76,9 +76,10 @@ typedef struct LinkCellSt {
    real_t localMin[3], localMax[3], boxSize[3], invBoxSize[3];
    int* nAtoms;           /* host copy; refreshed from the device by sumAtoms */
    int maxAtoms;          /* slot capacity per cell */
+   int *boxIDLookUp, *boxIDLookUpReverse;   /* -H: Hilbert numbering of the local cells (linkCells.h:27-28); NULL otherwise */
    CellGeom geom;
 } LinkCell;
-LinkCell* initLinkCells(const Domain* domain, real_t cutoff);
+LinkCell* initLinkCells(const Domain* domain, real_t cutoff, int useHilbert);
 void destroyLinkCells(LinkCell** boxes);
 int getNeighborBoxes(LinkCell* boxes, int iBox, int* nbrBoxes);
 int getBoxFromTuple(LinkCell* boxes, int x, int y, int z);

@@ -119,8 +119,8 @@ SimFlat* initSimulationHost(Command cmd)
    }
    else { printf("Error: You have to specify a valid method: -m [thread_atom,thread_atom_nl,cta_cell]\n"); exit(-1); }
    sim->useNL = sim->method == THREAD_ATOM_NL;
-   if (cmd.ljInterpolation || cmd.spline || cmd.doHilbert) {
-      printf("Error: -I, -P and -H are outside this build's scope (SURVEY.md section 8f).\n"); exit(-1);
+   if (cmd.ljInterpolation || cmd.spline) {
+      printf("Error: -I and -P are outside this build's scope (SURVEY.md section 8f).\n"); exit(-1);
    }
    /* -L (CoMD.c:250-255, ljForce.c:141): pairlist bits for the CTA-per-cell LJ kernel; same skin, cells and rebuild rule as the lists */
    sim->usePairlist = cmd.usePairlist;
@@ -139,7 +139,7 @@ SimFlat* initSimulationHost(Command cmd)
    sim->skinDistance = sim->useNL ? sim->pot->cutoff * cmd.relativeSkinDistance : 0.0;
    if (sim->useNL && printRank() && !cmd.quiet) printf("Skin-Distance: %f\n", sim->skinDistance);
    if (sim->useNL && sim->skinDistance <= 0.0) { printf("Error: the *_nl methods need a positive skin distance (-S)\n"); exit(-1); }
-   sim->boxes = initLinkCells(sim->domain, sim->pot->cutoff + sim->skinDistance);
+   sim->boxes = initLinkCells(sim->domain, sim->pot->cutoff + sim->skinDistance, cmd.doHilbert);
 
    int cap = cmd.maxAtoms;
    if (cap <= 0) {
@@ -187,6 +187,7 @@ SimFlat* initSimulation(Command cmd)
       for (int j = 0; j < 27; ++j) if (nbr[j] != iBox) nbrTable[iBox * 27 + c++] = nbr[j];
    }
    cfg.neighborCells = nbrTable;
+   cfg.boxIDLookUp = sim->boxes->boxIDLookUp; cfg.boxIDLookUpReverse = sim->boxes->boxIDLookUpReverse;
    cfg.skinDistance = sim->skinDistance; cfg.maxNeighbors = cmd.maxNeighbors; cfg.usePairlist = sim->usePairlist;
    cfg.latticeConstant = cmd.lat < 0.0 ? sim->pot->lat : cmd.lat;
    AllocateGpu(&sim->gpu, &cfg);

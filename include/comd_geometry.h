@@ -20,6 +20,10 @@ typedef struct CellGeom {
    int    g[3];            /* local grid */
    int    nLocal, nTotal;
    double lmin[3], lmax[3], inv[3];
+   /* optional renumbering of the LOCAL cells (space-filling curve, linkCells.c:160-178 boxIDLookUp / boxIDLookUpReverse):
+    * lookup[ix + gx*(iy + gy*iz)] = cell id, reverse[id] = ix + gx*(iy + gy*iz).  NULL: natural order.  Halo cells keep their numbers. */
+   const int* lookup;
+   const int* reverse;
 } CellGeom;
 
 /* Cell id of grid tuple (ix,iy,iz), each in [-1, g]; halo slabs are numbered after the local cells
@@ -34,7 +38,8 @@ COMD_HD int comdBoxFromTuple(const CellGeom* c, int ix, int iy, int iz)
    if (iy == -1) return base + 2*gz*gy + iz*(gx+2) + (ix+1);
    if (ix == gx) return base + gy*gz + iz*gy + iy;
    if (ix == -1) return base + iz*gy + iy;
-   return ix + gx*(iy + gy*iz);
+   const int idx = ix + gx*(iy + gy*iz);
+   return c->lookup ? c->lookup[idx] : idx;
 }
 
 /* Cell that owns position (x,y,z).  Inside the local domain the result is always a local cell (an atom
@@ -65,7 +70,8 @@ COMD_HD void comdTupleFromBox(const CellGeom* c, int iBox, int* ixp, int* iyp, i
    const int gx = c->g[0], gy = c->g[1], gz = c->g[2];
    int ix, iy, iz;
    if (iBox < c->nLocal) {
-      ix = iBox % gx; iy = (iBox / gx) % gy; iz = iBox / (gx*gy);
+      const int idx = c->reverse ? c->reverse[iBox] : iBox;
+      ix = idx % gx; iy = (idx / gx) % gy; iz = idx / (gx*gy);
    } else {
       int ink = iBox - c->nLocal;
       if (ink < 2*gy*gz) {

@@ -59,6 +59,8 @@ typedef struct LinkCellGpu {
    int    gridSize[3];
    real_t localMin[3], localMax[3], invBoxSize[3];
    int*   nAtoms;                      /* device [nTotalBoxes] */
+   int*   boxIDLookUp;                 /* device [nLocalBoxes] or NULL: -H renumbering of the local cells, tuple index -> id (gpu_types.h:114) */
+   int*   boxIDLookUpReverse;          /* device [nLocalBoxes] or NULL: id -> tuple index (gpu_types.h:115 stores an int3) */
 } LinkCellGpu;
 
 /* gpu_types.h:120-146 NeighborListGpu.  Verlet lists for the *_nl methods: every atom within cutoff + skinDistance of a local
@@ -138,6 +140,7 @@ typedef struct GpuConfig {
    real_t phiX0, phiInvDx, rhoX0, rhoInvDx, fX0, fInvDx;
    const real_t *phiValues, *rhoValues, *fValues; /* host, n+3 entries each, element 0 = values[-1] */
    const int* neighborCells;                      /* host [nLocalBoxes*27] */
+   const int *boxIDLookUp, *boxIDLookUpReverse;   /* host [nLocalBoxes] each, or NULL (natural cell order) */
    real_t skinDistance;                           /* > 0: allocate Verlet lists (AllocateGpu's third argument, gpu_utility.c:165) */
    int    usePairlist;                            /* with skinDistance > 0: pairlist bits for LJ cta_cell instead of lists (CoMD.c:250-268) */
    int    maxNeighbors;                           /* list rows per atom; 0 = derive from cutoff + skin and the FCC density */

@@ -101,10 +101,15 @@ def host_mode(pkg, orc, transport, rank, world, grid, eam, n):
 def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async):
     import torch
     pkg.setup_gpu(0, rank)
+    hilbert = method.endswith("+H")                          # "+H": Hilbert numbering of the link cells on every rank
+    if hilbert:
+        method = method[:-2]
     pairlist = method == "cta_cell_pairlist"
     if pairlist:
         method = "cta_cell"
     args = ["-x", n, "-y", n, "-z", n, "-i", grid[0], "-j", grid[1], "-k", grid[2], "-r", 0.1, "-m", method, "-a", use_async] + (["-e"] if eam else [])
+    if hilbert:
+        args += ["-H"]
     if pairlist:
         args += ["-L", "-S", 0.03]
         method = "cta_cell_nl"                               # below: run long, expect rebuilds

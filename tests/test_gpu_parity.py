@@ -422,3 +422,29 @@ def test_runs_are_bit_reproducible(gpu, eam, n, method):
     for a, b in zip(out[0][:3], out[1][:3]):
         assert np.array_equal(a, b)
     assert out[0][3] == out[1][3]
+
+
+# ---------------------------------------------------------------- Hilbert cell numbering (-H)
+@pytest.mark.parametrize("eam,n,method", [(0, (12, 10, 14), "thread_atom"), (0, 12, "cta_cell"), (0, 14, "thread_atom_nl"), (1, (9, 12, 7), "cta_cell"),
+                                          (1, 10, "thread_atom"), (1, 12, "thread_atom_nl")])
+def test_hilbert_numbering_changes_nothing_but_the_cell_ids(gpu, orc, eam, n, method):
+    """-H renumbers the local link cells along a Hilbert curve: which atoms share a cell, their order inside it (gid) and the order in
+    which a cell's 27 neighbours are visited are untouched.  The sums taken over ALL atoms (centre-of-mass velocity and temperature at
+    start-up on the host, the energy reduction on the device) run in cell order, so they move in their last bits and with them the
+    momenta; everything must still agree with the natural numbering and with the oracle to round-off after 25 steps (overlap mode on,
+    lists rebuilt on the way)."""
+    out = []
+    for extra in ([], ["-H"]):
+        with gpu.Simulation(_args(n, eam, 0.1, method, ["-a", 1] + extra)) as sim:
+            sim.step(25)
+            out.append((sim.gather(0), sim.gather(1), sim.gather(2), sim.gather(3), sim.energy()))
+    r0, p0, f0, e0, en0 = out[0]
+    r1, p1, f1, e1, en1 = out[1]
+    assert np.abs(r0 - r1).max() < 1e-12 and np.abs(p0 - p1).max() < 1e-12 * np.abs(p0).max()
+    assert np.abs(f0 - f1).max() < 1e-11 * np.abs(f0).max() and np.abs(e0 - e1).max() < 1e-11
+    assert abs(en0[0] - en1[0]) / en0[2] < 1e-13 and abs(en0[1] - en1[1]) / en0[2] < 1e-13 and en0[2] == en1[2]
+    o = orc.Oracle(n, eam=eam, delta=0.1)
+    o.step(25)
+    fo = o.gather(orc.F)
+    assert np.abs(f1 - fo).max() <= 1e-9 * np.abs(fo).max()
+    assert abs((en1[0] + en1[1]) - sum(o.energy())) / en1[2] < TOL["energy_per_atom_trace"]

@@ -167,3 +167,32 @@ def test_eam_tables_of_host_and_oracle_agree(pkg, orc, extra, pot_name):
         assert np.array_equal(v, ov)
         assert v[0] == v[1] and v[-1] == v[-2] == v[-3]      # eam.c:510-513 padding
     sim.close()
+
+
+@pytest.mark.parametrize("n,eam", [(8, 1), ((12, 9, 14), 0), ((7, 6, 9), 1)])
+def test_hilbert_numbering_is_a_bijection_and_local(pkg, n, eam):
+    """-H: local cells are renumbered along a Hilbert curve (any grid, the reference: power-of-two grids only, linkCells.c:151-178).
+    tuple -> id -> tuple is the identity, ids are dense, consecutive ids are face neighbours wherever the enclosing power-of-two cube
+    is full (always for a power-of-two grid), and the halo cells keep their numbers."""
+    nx, ny, nz = (n, n, n) if isinstance(n, int) else n
+    args = ["-x", nx, "-y", ny, "-z", nz] + (["-e"] if eam else [])
+    plain = pkg.Simulation(args, host_only=True)
+    hil = pkg.Simulation(args + ["-H"], host_only=True)
+    gx, gy, gz = hil.grid
+    ids = np.array([[[hil.box_from_tuple(ix, iy, iz) for iz in range(gz)] for iy in range(gy)] for ix in range(gx)])
+    assert sorted(ids.ravel()) == list(range(gx * gy * gz))
+    where = {int(ids[ix, iy, iz]): (ix, iy, iz) for ix in range(gx) for iy in range(gy) for iz in range(gz)}
+    steps = [sum(abs(a - b) for a, b in zip(where[i], where[i + 1])) for i in range(gx * gy * gz - 1)]
+    if all(v & (v - 1) == 0 for v in (gx, gy, gz)) and gx == gy == gz:
+        assert max(steps) == 1
+    assert np.mean(np.array(steps) == 1) > 0.6          # a Hilbert walk with the cells outside the grid skipped
+    for t in [(-1, 0, 0), (gx, 1, 1), (0, -1, gz - 1), (1, gy, 0), (0, 0, -1), (gx, gy, gz), (-1, -1, -1)]:
+        assert hil.box_from_tuple(*t) == plain.box_from_tuple(*t)
+    # every atom sits in the cell its coordinates name, under either numbering
+    for sim in (plain, hil):
+        c = sim.cells()
+        for b in range(0, sim.n_local_boxes, 7):
+            for i in range(c["nAtoms"][b]):
+                assert sim.box_from_coord((c["rx"][b, i], c["ry"][b, i], c["rz"][b, i])) == b
+    assert plain.cells()["nAtoms"][:plain.n_local_boxes].sum() == hil.cells()["nAtoms"][:hil.n_local_boxes].sum()
+    plain.close(); hil.close()

@@ -54,7 +54,8 @@ def test_host_logic_two_processes_gloo(grid, eam, n):
                                                            ((2, 1, 1), 1, 12, "thread_atom_nl", 0), ((1, 2, 1), 0, 22, "thread_atom_nl", 1),
                                                            ((1, 1, 2), 0, 22, "cta_cell_pairlist", 1),
                                                            # three ranks on an axis: minus and plus neighbours are different ranks
-                                                           ((3, 1, 1), 1, 12, "cta_cell", 1), ((1, 1, 3), 0, 21, "thread_atom", 0), ((1, 3, 1), 1, 14, "thread_atom_nl", 1)])
+                                                           ((3, 1, 1), 1, 12, "cta_cell", 1), ((1, 1, 3), 0, 21, "thread_atom", 0), ((1, 3, 1), 1, 14, "thread_atom_nl", 1),
+                                                           ((2, 1, 2), 1, 12, "cta_cell+H", 1), ((2, 1, 1), 0, 22, "thread_atom_nl+H", 0)])
 def test_gpu_path_multi_rank_shared_device(grid, eam, n, method, use_async):
     outs = _launch("gpu", grid, eam, n, extra=(method, use_async))
     assert "gpu-mode OK" in outs[0]
