@@ -181,6 +181,15 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
       uploadTable(&sim->eam_pot.phi, cfg->nPhi, cfg->phiX0, cfg->phiInvDx, cfg->phiValues);
       uploadTable(&sim->eam_pot.rho, cfg->nRho, cfg->rhoX0, cfg->rhoInvDx, cfg->rhoValues);
       uploadTable(&sim->eam_pot.f,   cfg->nF,   cfg->fX0,   cfg->fInvDx,   cfg->fValues);
+      if (cfg->phiSpline && cfg->rhoSpline) {             // gpu_utility.c:247-249, 478-500
+         auto up = [](InterpolationSplineObjectGpu* t, int n, real_t x0, real_t invDx, const real_t* host) {
+            t->n = n; t->x0 = (float)x0; t->xn = (float)(x0 + n / invDx); t->invDx = (float)invDx; t->invDxXx0 = (float)(invDx * x0);
+            t->coefficients = dalloc<real_t>((size_t)4 * n, false);
+            HIP_CHECK(hipMemcpy(t->coefficients, host, (size_t)4 * n * sizeof(real_t), hipMemcpyHostToDevice));
+         };
+         up(&sim->eam_pot.phiS, cfg->nPhi, cfg->phiX0, cfg->phiInvDx, cfg->phiSpline);
+         up(&sim->eam_pot.rhoS, cfg->nRho, cfg->rhoX0, cfg->rhoInvDx, cfg->rhoSpline);
+      }
       sim->eam_pot.rhobar = dalloc<real_t>(slots);
       sim->eam_pot.dfEmbed = dalloc<real_t>(slots);
    }
@@ -314,7 +323,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.list, sim->atoms.neighborList.nNeighbors, sim->atoms.neighborList.lastR.x,
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
-                    sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse };
+                    sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
@@ -470,15 +479,41 @@ static EamArgs makeEamArgs(SimGpu* sim, int num_cells, int* cells_list)
    a.nCells = num_cells; a.cap = sim->maxAtoms;
    a.rc2 = sim->eam_pot.cutoff * sim->eam_pot.cutoff;
    a.phi = sim->eam_pot.phi; a.rho = sim->eam_pot.rho; a.f = sim->eam_pot.f;
+   a.phiS = sim->eam_pot.phiS; a.rhoS = sim->eam_pot.rhoS;
    return a;
 }
 
 template <int STEP>
-static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int method, hipStream_t st)
+static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int method, hipStream_t st, int spline)
 {
    if (num_cells <= 0) return;
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
    ForceTimer timer(st);
+   if (spline) {
+      // -P (gpu_kernels.cu:164-226): cubic splines in r^2 for phi and rho, coefficient tables read through L2 (16 KB each for funcfl)
+      if (!a.phiS.coefficients || !a.rhoS.coefficients) { fprintf(stderr, "eamForce: spline != 0 but no spline tables were given to AllocateGpu\n"); exit(-1); }
+      if (method == CTA_CELL) {
+         const int wide = sim->eam_pot.cutoff > 5.2;          // same stencil-list capacities as the quadratic path (funcfl / setfl cutoffs)
+         int grid = ceilDiv(num_cells, EAM_CTA_WAVES);
+         if (grid > 2048) grid = 2048;
+         if (grid < 8) grid = 8;
+         if (!wide) {
+            const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, 0);
+            HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+         } else {
+            const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
+            HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+         }
+      } else if (method == THREAD_ATOM || method == WARP_ATOM) {
+         hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, true>), dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);
+      } else {
+         fprintf(stderr, "eamForce: the spline tables (-P) are implemented for the cell methods (thread_atom, cta_cell)\n"); exit(-1);
+      }
+      LAUNCH_CHECK();
+      return;
+   }
    if ((method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat == 2) {
       NeighborListGpu* n = &sim->atoms.neighborList;
       (void)nlView(sim);
@@ -507,28 +542,26 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (tablesInLds) {
          const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, tableBytes);
          static bool attrSet = false;
-         if (!attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = true; }
-         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+         if (!attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = true; }
+         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
       } else {
          const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
          static bool attrSet = false;
-         if (!attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = true; }
-         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+         if (!attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = true; }
+         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
       }
    } else {
-      hipLaunchKernelGGL(EAM_Force_thread_atom<STEP>, dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);
+      hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, false>), dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);
    }
    LAUNCH_CHECK();
 }
 
-static void checkSpline(int spline) { if (spline) { fprintf(stderr, "eamForce: spline tables (-P) are out of scope\n"); exit(-1); } }
-
 extern "C" void eamForce1GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline)
-{ checkSpline(spline); launchEamPair<1>(sim, num_cells, cells_list, method, S(stream)); }
+{ launchEamPair<1>(sim, num_cells, cells_list, method, S(stream), spline); }
 
 extern "C" void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline)
 {
-   checkSpline(spline); (void)method;
+   (void)spline; (void)method;              /* F(rhobar) is quadratic in both modes (gpu_utility.c:443) */
    if (num_cells <= 0) return;
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
    ForceTimer timer(S(stream));
@@ -537,7 +570,7 @@ extern "C" void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, i
 }
 
 extern "C" void eamForce3GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline)
-{ checkSpline(spline); launchEamPair<3>(sim, num_cells, cells_list, method, S(stream)); }
+{ launchEamPair<3>(sim, num_cells, cells_list, method, S(stream), spline); }
 
 extern "C" void eamForce1Gpu(SimGpu* sim, int method, int spline) { eamForce1GpuAsync(sim, sim->boxes.nLocalBoxes, nullptr, method, nullptr, spline); }
 extern "C" void eamForce2Gpu(SimGpu* sim, int method, int spline) { eamForce2GpuAsync(sim, sim->boxes.nLocalBoxes, nullptr, method, nullptr, spline); }

@@ -152,6 +152,23 @@ __device__ __forceinline__ void interpolatePair(const double* __restrict__ v, co
    }
 }
 
+// Cubic spline in r^2 (reference gpu_common.h:95-129): value f(r) and (1/r) df/dr -- no square root on the path except the
+// single-precision one that picks the table interval.
+__device__ __forceinline__ void interpolateSpline(const InterpolationSplineObjectGpu& t, double r2, double& f, double& df)
+{
+   float r = __builtin_sqrtf((float)r2);
+   r = fmaxf(r, t.x0);
+   r = fminf(r, t.xn);
+   r = r * t.invDx - t.invDxXx0;
+   int ii = (int)floorf(r);
+   ii = ii < t.n - 1 ? ii : t.n - 1;                          // r == xn lands on the last interval
+   const double* __restrict__ c = t.coefficients + 4 * ii;
+   const double a = c[0], b = c[1], cc = c[2], d = c[3];
+   const double tmp = a * r2 + b;
+   f = (tmp * r2 + cc) * r2 + d;
+   df = 2.0 * ((3.0 * tmp - b) * r2 + cc);
+}
+
 __device__ __forceinline__ CellGeom makeGeom(const LinkCellGpu& b)
 {
    CellGeom c;

@@ -6,7 +6,8 @@
 //   pass 1: e_i = 1/2 sum phi(r), rhobar_i = sum rho(r), f_i -= phi'(r) d/r          (0 < r^2 <= rc^2)
 //   pass 2: dfEmbed_i = F'(rhobar_i), e_i += F(rhobar_i)
 //   pass 3: f_i -= (F'_i + F'_j) rho'(r) d/r
-// Tables are the reference's default quadratic interpolation (gpu_common.h:48-86); the -P spline mode is out of scope.
+// Tables: the reference's default quadratic interpolation in r (gpu_common.h:48-86), or with SPLINE its cubic splines in r^2
+// (-P, gpu_common.h:95-129: value and (1/r) d/dr straight from r^2, read through L2); F(rhobar) is quadratic in both modes.
 //
 //  thread_atom : one thread per cell slot (cell*cap + i), tables read through L1/L2.
 //  cta_cell    : persistent workgroups of 4 waves, each wave owns one cell at a time.  phi/rho tables live in LDS for the
@@ -26,11 +27,12 @@ struct EamArgs {
    int nCells, cap;
    double rc2;
    InterpolationObjectGpu phi, rho, f;
+   InterpolationSplineObjectGpu phiS, rhoS;
 };
 
 // ---------------------------------------------------------------------------------------------------
 // thread per slot; grid ceil(nCells*cap/256) x 256
-template <int STEP>
+template <int STEP, bool SPLINE>
 __global__ __launch_bounds__(256)
 void EAM_Force_thread_atom(EamArgs a)
 {
@@ -56,12 +58,18 @@ void EAM_Force_thread_atom(EamArgs a)
          double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
          double r2 = dx*dx + dy*dy + dz*dz;
          if (r2 <= a.rc2 && r2 > 0.0) {
-            double ir = rsqrt64(r2), r = r2 * ir;
             double rho, drho, dphi;
-            interpolate(rhoT, r, rho, drho);
-            if (STEP == 1) { double phi; interpolate(phiT, r, phi, dphi); e += phi; rb += rho; }
-            else           { dphi = (dfi + a.dfEmbed[base + j]) * drho; }
-            dphi *= ir;
+            if (SPLINE) {                                  // drho, dphi are (1/r) d/dr already
+               interpolateSpline(a.rhoS, r2, rho, drho);
+               if (STEP == 1) { double phi; interpolateSpline(a.phiS, r2, phi, dphi); e += phi; rb += rho; }
+               else           { dphi = (dfi + a.dfEmbed[base + j]) * drho; }
+            } else {
+               double ir = rsqrt64(r2), r = r2 * ir;
+               interpolate(rhoT, r, rho, drho);
+               if (STEP == 1) { double phi; interpolate(phiT, r, phi, dphi); e += phi; rb += rho; }
+               else           { dphi = (dfi + a.dfEmbed[base + j]) * drho; }
+               dphi *= ir;
+            }
             fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
          }
       }
@@ -105,7 +113,7 @@ void EAM_Force_embed(EamArgs a)
 
 // A cell whose 27-cell stencil holds more than EAM_CTA_MAXCAND atoms (small boxes have larger cells) is handled by the
 // same wave in the thread-per-atom form: lane = i atom, neighbours streamed from global memory, same tables.
-template <int STEP>
+template <int STEP, bool SPLINE>
 __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int lane, const TableView& rhoT, const TableView& phiT, bool sameGrid)
 {
    const int ni = a.nAtoms[iBox];
@@ -123,18 +131,24 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
             const double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
             const double r2 = dx*dx + dy*dy + dz*dz;
             if (r2 <= a.rc2 && r2 > 0.0) {
-               const double ir = rsqrt64(r2), r = r2 * ir;
                double rho, drho, dphi;
-               if (STEP == 1) {
-                  double phi;
-                  if (sameGrid) interpolatePair(rhoT.v, rhoT, r, phi, dphi, rho, drho);
-                  else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
-                  e += phi; rb += rho;
+               if (SPLINE) {
+                  interpolateSpline(a.rhoS, r2, rho, drho);
+                  if (STEP == 1) { double phi; interpolateSpline(a.phiS, r2, phi, dphi); e += phi; rb += rho; }
+                  else           { dphi = (dfi + a.dfEmbed[base + j]) * drho; }
                } else {
-                  interpolate(rhoT, r, rho, drho);
-                  dphi = (dfi + a.dfEmbed[base + j]) * drho;
+                  const double ir = rsqrt64(r2), r = r2 * ir;
+                  if (STEP == 1) {
+                     double phi;
+                     if (sameGrid) interpolatePair(rhoT.v, rhoT, r, phi, dphi, rho, drho);
+                     else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
+                     e += phi; rb += rho;
+                  } else {
+                     interpolate(rhoT, r, rho, drho);
+                     dphi = (dfi + a.dfEmbed[base + j]) * drho;
+                  }
+                  dphi *= ir;
                }
-               dphi *= ir;
                fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
             }
          }
@@ -144,7 +158,7 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
    }
 }
 
-template <int STEP, int MAXCAND, bool LDS_TABLES>
+template <int STEP, int MAXCAND, bool LDS_TABLES, bool SPLINE>
 __global__ __launch_bounds__(EAM_CTA_THREADS)
 void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
 {
@@ -204,7 +218,7 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
       __builtin_amdgcn_wave_barrier();
       const int nCand = uniform(sOff[27]);
       const int ni = uniform(sOff[1]);
-      if (nCand > MAXCAND) { eamCellDirect<STEP>(a, iBox, lane, rhoT, phiT, sameGrid); continue; }
+      if (nCand > MAXCAND) { eamCellDirect<STEP, SPLINE>(a, iBox, lane, rhoT, phiT, sameGrid); continue; }
 
       // (2) stage positions [and F'] of the stencil cells, in groups of GROUP rounds with all loads in flight together
       constexpr int GROUP = 4;                      // 4 rounds x (3-4 loads) in flight; 7 rounds cost 60 more VGPRs and a wave per SIMD
@@ -281,20 +295,33 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
             const double ax = xA - sx[jA], ay = yA - sy[jA], az = zA - sz[jA];
             const double bx = xB - sx[jB], by = yB - sy[jB], bz = zB - sz[jB];
             const double sA = hA ? ax*ax + ay*ay + az*az : a.rc2, sB = hB ? bx*bx + by*by + bz*bz : a.rc2;
-            const double irA = rsqrt64(sA), irB = rsqrt64(sB);
-            const double rA = sA * irA, rB = sB * irB;
             double rhoA, drhoA, dphiA, rhoB, drhoB, dphiB;
-            if (STEP == 1) {
-               double phiA, phiB;
-               if (sameGrid) { interpolatePair(sRho, rhoT, rA, phiA, dphiA, rhoA, drhoA); interpolatePair(sRho, rhoT, rB, phiB, dphiB, rhoB, drhoB); }
-               else { interpolate(rhoT, rA, rhoA, drhoA); interpolate(phiT, rA, phiA, dphiA); interpolate(rhoT, rB, rhoB, drhoB); interpolate(phiT, rB, phiB, dphiB); }
-               part[0][3] += hA ? phiA : 0.0; part[0][4] += hA ? rhoA : 0.0;
-               part[1][3] += hB ? phiB : 0.0; part[1][4] += hB ? rhoB : 0.0;
+            if (SPLINE) {                                   // cubic splines in r^2: (1/r) d/dr directly, no square root
+               interpolateSpline(a.rhoS, sA, rhoA, drhoA); interpolateSpline(a.rhoS, sB, rhoB, drhoB);
+               if (STEP == 1) {
+                  double phiA, phiB;
+                  interpolateSpline(a.phiS, sA, phiA, dphiA); interpolateSpline(a.phiS, sB, phiB, dphiB);
+                  part[0][3] += hA ? phiA : 0.0; part[0][4] += hA ? rhoA : 0.0;
+                  part[1][3] += hB ? phiB : 0.0; part[1][4] += hB ? rhoB : 0.0;
+               } else {
+                  dphiA = (dfA + a.dfEmbed[sSlot[jA]]) * drhoA; dphiB = (dfB + a.dfEmbed[sSlot[jB]]) * drhoB;
+               }
+               dphiA = hA ? dphiA : 0.0; dphiB = hB ? dphiB : 0.0;
             } else {
-               interpolate(rhoT, rA, rhoA, drhoA); interpolate(rhoT, rB, rhoB, drhoB);
-               dphiA = (dfA + a.dfEmbed[sSlot[jA]]) * drhoA; dphiB = (dfB + a.dfEmbed[sSlot[jB]]) * drhoB;
+               const double irA = rsqrt64(sA), irB = rsqrt64(sB);
+               const double rA = sA * irA, rB = sB * irB;
+               if (STEP == 1) {
+                  double phiA, phiB;
+                  if (sameGrid) { interpolatePair(sRho, rhoT, rA, phiA, dphiA, rhoA, drhoA); interpolatePair(sRho, rhoT, rB, phiB, dphiB, rhoB, drhoB); }
+                  else { interpolate(rhoT, rA, rhoA, drhoA); interpolate(phiT, rA, phiA, dphiA); interpolate(rhoT, rB, rhoB, drhoB); interpolate(phiT, rB, phiB, dphiB); }
+                  part[0][3] += hA ? phiA : 0.0; part[0][4] += hA ? rhoA : 0.0;
+                  part[1][3] += hB ? phiB : 0.0; part[1][4] += hB ? rhoB : 0.0;
+               } else {
+                  interpolate(rhoT, rA, rhoA, drhoA); interpolate(rhoT, rB, rhoB, drhoB);
+                  dphiA = (dfA + a.dfEmbed[sSlot[jA]]) * drhoA; dphiB = (dfB + a.dfEmbed[sSlot[jB]]) * drhoB;
+               }
+               dphiA = hA ? dphiA * irA : 0.0; dphiB = hB ? dphiB * irB : 0.0;
             }
-            dphiA = hA ? dphiA * irA : 0.0; dphiB = hB ? dphiB * irB : 0.0;
             part[0][0] -= dphiA * ax; part[0][1] -= dphiA * ay; part[0][2] -= dphiA * az;
             part[1][0] -= dphiB * bx; part[1][1] -= dphiB * by; part[1][2] -= dphiB * bz;
          }

@@ -58,7 +58,7 @@ Command parseCommandLine(int argc, char** argv)
       { "gpuAsync",     'a', 1, 'i', &cmd.gpuAsync,       0, "communicaton hiding optimization using streams" },
       { "gpuProfile",   's', 0, 'i', &cmd.gpuProfile,     0, "profiling mode: reboxing disabled, single kernel run" },
       { "ljInterpolation", 'I', 0, 'i', &cmd.ljInterpolation, 0, "Lennard-Jones by table interpolation (not supported)" },
-      { "spline",       'P', 0, 'i', &cmd.spline,         0, "spline interpolation (not supported)" },
+      { "spline",       'P', 0, 'i', &cmd.spline,         0, "cubic-spline EAM tables in r^2 (thread_atom, cta_cell)" },
       { "usePairlist",  'L', 0, 'i', &cmd.usePairlist,    0, "pairlists for cta_cell LJ" },
       { "maxAtoms",      0,  1, 'i', &cmd.maxAtoms,       0, "link-cell slot capacity (0 = from the lattice)" },
       { "maxNeighbors",  0,  1, 'i', &cmd.maxNeighbors,   0, "neighbour-list rows per atom for *_nl (0 = from cutoff + skin)" },

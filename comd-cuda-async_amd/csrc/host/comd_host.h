@@ -137,12 +137,15 @@ typedef struct EamPotentialSt {
    void (*print)(FILE* file, BasePotential* pot);
    void (*destroy)(BasePotential** pot);
    InterpolationObject *phi, *rho, *f;
+   real_t *phiSpline, *rhoSpline;     /* -P: 4 * n cubic-spline coefficients in r^2 each (gpu_utility.c:377-430), else NULL */
    struct HaloExchangeSt* forceExchange;
 } EamPotential;
 
 BasePotential* initLjPot(void);
 BasePotential* initEamPot(const char* dir, const char* file, const char* type);
 void interpolate(InterpolationObject* table, real_t r, real_t* f, real_t* df);
+real_t* initSplineCoefficients(int n, const real_t* values, real_t x0, real_t invDx);   /* malloc'd, 4 * n */
+void eamUseSplines(BasePotential* pot);                                                /* fill phiSpline / rhoSpline */
 
 typedef struct SpeciesDataSt { char name[3]; int atomicNo; real_t mass; } SpeciesData;
 typedef struct ValidateSt { double eTot0; int nAtoms0; } Validate;

@@ -159,6 +159,53 @@ static void eamPrint(FILE* file, BasePotential* pot)
    fprintf(file, "  Cutoff          : %lg Angstroms\n", e->cutoff);
 }
 
+/* gpu_utility.c:377-430 initSplineCoefficients: natural cubic spline (Numerical Recipes 3.3) through the table samples as a function
+ * of x = r^2 -- second derivative 0 at the first knot, first derivative 0 at the last -- returned as {a,b,c,d} per interval so that
+ * f = ((a x + b) x + c) x + d.  values[0..n] are read (values[n] is the table's trailing pad). */
+real_t* initSplineCoefficients(int n, const real_t* values, real_t x0, real_t invDx)
+{
+   real_t* u = (real_t*)malloc((size_t)n * sizeof(real_t));
+   real_t* d2 = (real_t*)malloc((size_t)(n + 1) * sizeof(real_t));
+   d2[0] = 0.0; u[0] = 0.0;
+   for (int i = 1; i < n; ++i) {
+      const real_t xi = (x0 + i / invDx) * (x0 + i / invDx);
+      const real_t xp = (x0 + (i - 1) / invDx) * (x0 + (i - 1) / invDx);
+      const real_t xn = (x0 + (i + 1) / invDx) * (x0 + (i + 1) / invDx);
+      const real_t sig = (xi - xp) / (xn - xp);
+      const real_t p = sig * d2[i - 1] + 2.0;
+      d2[i] = (sig - 1.0) / p;
+      u[i] = (values[i + 1] - values[i]) / (xn - xi) - (values[i] - values[i - 1]) / (xi - xp);
+      u[i] = (6.0 * u[i] / (xn - xp) - sig * u[i - 1]) / p;
+   }
+   {
+      const real_t xn = (x0 + n / invDx) * (x0 + n / invDx);
+      const real_t xnp = (x0 + (n - 1) / invDx) * (x0 + (n - 1) / invDx);
+      const real_t qn = 0.5;
+      const real_t un = (-3.0 / (xn - xnp)) * (values[n] - values[n - 1]) / (xn - xnp);
+      d2[n] = (un - qn * u[n - 1]) / (qn * d2[n - 1] + 1.0);
+   }
+   for (int i = n - 1; i >= 0; --i) d2[i] = d2[i] * d2[i + 1] + u[i];
+   real_t* c = (real_t*)malloc((size_t)4 * n * sizeof(real_t));
+   for (int i = 0; i < n; ++i) {
+      const real_t x1 = (x0 + i / invDx) * (x0 + i / invDx);
+      const real_t x2 = (x0 + (i + 1) / invDx) * (x0 + (i + 1) / invDx);
+      const real_t h = x2 - x1, s1 = d2[i], s2 = d2[i + 1], y1 = values[i], y2 = values[i + 1];
+      c[4 * i]     = 1.0 / (6.0 * h) * (s2 - s1);
+      c[4 * i + 1] = 1.0 / (2.0 * h) * (x2 * s1 - x1 * s2);
+      c[4 * i + 2] = 1.0 / h * (1.0 / 6.0 * (-3 * x2 * x2 + h * h) * s1 + 1.0 / 6.0 * (3 * x1 * x1 - h * h) * s2 - y1 + y2);
+      c[4 * i + 3] = 1 / h * (x2 * y1 - x1 * y2 + 1.0 / 6.0 * s1 * (x2 * x2 * x2 - x2 * h * h) + 1.0 / 6.0 * s2 * (-x1 * x1 * x1 + x1 * h * h));
+   }
+   free(u); free(d2);
+   return c;
+}
+
+void eamUseSplines(BasePotential* bp)
+{
+   EamPotential* pot = (EamPotential*)bp;
+   pot->phiSpline = initSplineCoefficients(pot->phi->n, pot->phi->values, pot->phi->x0, pot->phi->invDx);
+   pot->rhoSpline = initSplineCoefficients(pot->rho->n, pot->rho->values, pot->rho->x0, pot->rho->invDx);
+}
+
 static void eamDestroy(BasePotential** pPot)
 {
    if (!pPot || !*pPot) return;
@@ -166,6 +213,7 @@ static void eamDestroy(BasePotential** pPot)
    destroyInterpolationObject(&pot->phi);
    destroyInterpolationObject(&pot->rho);
    destroyInterpolationObject(&pot->f);
+   free(pot->phiSpline); free(pot->rhoSpline);
    if (pot->forceExchange) destroyHaloExchange(&pot->forceExchange);
    free(pot);
    *pPot = NULL;

@@ -119,8 +119,13 @@ SimFlat* initSimulationHost(Command cmd)
    }
    else { printf("Error: You have to specify a valid method: -m [thread_atom,thread_atom_nl,cta_cell]\n"); exit(-1); }
    sim->useNL = sim->method == THREAD_ATOM_NL;
-   if (cmd.ljInterpolation || cmd.spline) {
-      printf("Error: -I and -P are outside this build's scope (SURVEY.md section 8f).\n"); exit(-1);
+   if (cmd.ljInterpolation) {
+      printf("Error: -I is outside this build's scope (SURVEY.md section 8f).\n"); exit(-1);
+   }
+   /* -P (CoMD.c:271, gpu_utility.c:474-500): cubic-spline tables in r^2 for phi and rho; the reference has them in its cell kernels */
+   sim->spline = cmd.spline;
+   if (sim->spline && (!cmd.doeam || (sim->method != THREAD_ATOM && sim->method != CTA_CELL))) {
+      printf("Error: -P applies to EAM with -m thread_atom or cta_cell.\n"); exit(-1);
    }
    /* -L (CoMD.c:250-255, ljForce.c:141): pairlist bits for the CTA-per-cell LJ kernel; same skin, cells and rebuild rule as the lists */
    sim->usePairlist = cmd.usePairlist;
@@ -128,6 +133,7 @@ SimFlat* initSimulationHost(Command cmd)
    sim->useNL = sim->useNL || sim->usePairlist;        /* frozen slots between rebuilds, positional halo refresh */
 
    sim->pot = initPotential(cmd.doeam, cmd.potDir, cmd.potName, cmd.potType);
+   if (sim->spline) eamUseSplines(sim->pot);
    real_t latticeConstant = cmd.lat;
    if (cmd.lat < 0.0) latticeConstant = sim->pot->lat;
    sanityChecks(cmd, sim->pot->cutoff, latticeConstant, sim->pot->latticeType);
@@ -175,6 +181,7 @@ SimFlat* initSimulation(Command cmd)
       cfg.nPhi = e->phi->n; cfg.phiX0 = e->phi->x0; cfg.phiInvDx = e->phi->invDx; cfg.phiValues = e->phi->values - 1;
       cfg.nRho = e->rho->n; cfg.rhoX0 = e->rho->x0; cfg.rhoInvDx = e->rho->invDx; cfg.rhoValues = e->rho->values - 1;
       cfg.nF = e->f->n;     cfg.fX0 = e->f->x0;     cfg.fInvDx = e->f->invDx;     cfg.fValues = e->f->values - 1;
+      cfg.phiSpline = e->phiSpline; cfg.rhoSpline = e->rhoSpline;
    } else {
       LjPotential* lj = (LjPotential*)sim->pot;
       cfg.ljCutoff = lj->cutoff; cfg.ljSigma = lj->sigma; cfg.ljEpsilon = lj->epsilon;

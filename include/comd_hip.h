@@ -45,10 +45,19 @@ typedef struct InterpolationObjectGpu {
 /* gpu_types.h:72-79 */
 typedef struct LjPotentialGpu { real_t cutoff, sigma, epsilon; } LjPotentialGpu;
 
-/* gpu_types.h:81-96 (spline tables: out of scope) */
+/* gpu_types.h:60-69: cubic spline in r^2 (-P, `spline` argument of eamForce*Gpu): coefficients {a,b,c,d} per table interval,
+ * f(r) = ((a r2 + b) r2 + c) r2 + d; the interval is picked with single-precision arithmetic as in the reference */
+typedef struct InterpolationSplineObjectGpu {
+   int     n;
+   float   x0, xn, invDx, invDxXx0;
+   real_t* coefficients;               /* device, 4 * n */
+} InterpolationSplineObjectGpu;
+
+/* gpu_types.h:81-96 */
 typedef struct EamPotentialGpu {
    real_t cutoff;
    InterpolationObjectGpu phi, rho, f;
+   InterpolationSplineObjectGpu phiS, rhoS;   /* allocated when GpuConfig.phiSpline / rhoSpline are given; F(rhobar) stays quadratic (gpu_utility.c:443) */
    real_t* rhobar;                     /* device [nTotalBoxes*maxAtoms] */
    real_t* dfEmbed;                    /* device [nTotalBoxes*maxAtoms] */
 } EamPotentialGpu;
@@ -139,6 +148,7 @@ typedef struct GpuConfig {
    int    nPhi, nRho, nF;                         /* table lengths (n, not n+3) */
    real_t phiX0, phiInvDx, rhoX0, rhoInvDx, fX0, fInvDx;
    const real_t *phiValues, *rhoValues, *fValues; /* host, n+3 entries each, element 0 = values[-1] */
+   const real_t *phiSpline, *rhoSpline;           /* host, 4*n spline coefficients each (initSplineCoefficients, gpu_utility.c:377-430), or NULL */
    const int* neighborCells;                      /* host [nLocalBoxes*27] */
    const int *boxIDLookUp, *boxIDLookUpReverse;   /* host [nLocalBoxes] each, or NULL (natural cell order) */
    real_t skinDistance;                           /* > 0: allocate Verlet lists (AllocateGpu's third argument, gpu_utility.c:165) */
@@ -202,7 +212,8 @@ void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, co
  * next evaluations feed no energy read, so they may skip the energy arithmetic; comdSetEnergyNeeded(1) (the default)
  * restores the reference behaviour of computing e[] on every call.  timestep() brackets all but its last step with it. */
 void comdSetEnergyNeeded(int on);
-/* eamForce{1,2,3}Gpu(SimGpu, method, spline), gpu_kernels.cu:154-249; spline must be 0 */
+/* eamForce{1,2,3}Gpu(SimGpu, method, spline), gpu_kernels.cu:154-249; spline != 0 needs the spline tables (GpuConfig.phiSpline/rhoSpline)
+ * and one of the cell methods (THREAD_ATOM, CTA_CELL) */
 void eamForce1Gpu(SimGpu* sim, int method, int spline);
 void eamForce2Gpu(SimGpu* sim, int method, int spline);
 void eamForce3Gpu(SimGpu* sim, int method, int spline);

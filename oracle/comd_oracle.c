@@ -98,6 +98,7 @@ struct OracleSim {
    double sigma, epsilon;
    /* EAM */
    Table phi, rho, F;
+   double *phiSpline, *rhoSpline;      /* -P (oracle_use_splines): 4 n coefficients each, else NULL */
    Rank* rk;
    double ePot, eKin, loopSeconds;
 };
@@ -474,6 +475,54 @@ static void ljForceRank(const OracleSim* s, Rank* k)
    k->ePot = ePot;
 }
 
+/* ---- -P: cubic splines in x = r^2 (gpu_utility.c:377-430 initSplineCoefficients, gpu_common.h:95-129 interpolateSpline) --------
+ * The reference has this mode on the GPU only (its CPU eamForce always interpolates quadratically), so these two functions restate
+ * device code and the results they check are PARITY-UNPINNED against reference output: none exists for -P. */
+static double* splineCoefficients(const Table* t)
+{
+   const int n = t->n; const double x0 = t->x0, invDx = t->invDx; const double* v = t->v;
+   double* u = (double*)malloc((size_t)n * sizeof(double));
+   double* y2 = (double*)malloc((size_t)(n + 1) * sizeof(double));
+   y2[0] = 0.0; u[0] = 0.0;                                  /* second derivative 0 at the first knot */
+   for (int i = 1; i < n; ++i) {
+      const double xi = (x0 + i / invDx) * (x0 + i / invDx), xp = (x0 + (i - 1) / invDx) * (x0 + (i - 1) / invDx), xn = (x0 + (i + 1) / invDx) * (x0 + (i + 1) / invDx);
+      const double sig = (xi - xp) / (xn - xp), p = sig * y2[i - 1] + 2.0;
+      y2[i] = (sig - 1.0) / p;
+      u[i] = (v[i + 1] - v[i]) / (xn - xi) - (v[i] - v[i - 1]) / (xi - xp);
+      u[i] = (6.0 * u[i] / (xn - xp) - sig * u[i - 1]) / p;
+   }
+   const double xN = (x0 + n / invDx) * (x0 + n / invDx), xNp = (x0 + (n - 1) / invDx) * (x0 + (n - 1) / invDx);
+   const double qn = 0.5, un = (-3.0 / (xN - xNp)) * (v[n] - v[n - 1]) / (xN - xNp);      /* first derivative 0 at the last knot */
+   y2[n] = (un - qn * u[n - 1]) / (qn * y2[n - 1] + 1.0);
+   for (int i = n - 1; i >= 0; --i) y2[i] = y2[i] * y2[i + 1] + u[i];
+   double* c = (double*)malloc((size_t)4 * n * sizeof(double));
+   for (int i = 0; i < n; ++i) {
+      const double x1 = (x0 + i / invDx) * (x0 + i / invDx), x2 = (x0 + (i + 1) / invDx) * (x0 + (i + 1) / invDx);
+      const double d1 = y2[i], d2 = y2[i + 1], y1 = v[i], yy2 = v[i + 1];
+      c[4*i]   = 1.0 / (6.0 * (x2 - x1)) * (d2 - d1);
+      c[4*i+1] = 1.0 / (2.0 * (x2 - x1)) * (x2 * d1 - x1 * d2);
+      c[4*i+2] = 1.0 / (x2 - x1) * (1.0/6.0 * (-3*x2*x2 + (x2-x1)*(x2-x1)) * d1 + 1.0/6.0 * (3*x1*x1 - (x2-x1)*(x2-x1)) * d2 - y1 + yy2);
+      c[4*i+3] = 1 / (x2 - x1) * (x2*y1 - x1*yy2 + 1.0/6.0 * d1 * (x2*x2*x2 - x2*(x2-x1)*(x2-x1)) + 1.0/6.0 * d2 * (-x1*x1*x1 + x1*(x2-x1)*(x2-x1)));
+   }
+   free(u); free(y2);
+   return c;
+}
+
+/* value and (1/r) d/dr at r^2; the interval is picked in single precision like the device code */
+static inline void splineEval(const Table* t, const double* c, double r2, double* f, double* df)
+{
+   float r = sqrtf((float)r2);
+   const float x0 = (float)t->x0, xn = (float)(t->x0 + t->n / t->invDx), invDx = (float)t->invDx, invDxXx0 = (float)(t->invDx * t->x0);
+   r = r > x0 ? r : x0; r = r < xn ? r : xn;
+   r = r * invDx - invDxXx0;
+   int ii = (int)floorf(r);
+   if (ii > t->n - 1) ii = t->n - 1;
+   const double a = c[4*ii], b = c[4*ii+1], cc = c[4*ii+2], d = c[4*ii+3];
+   const double tmp = a * r2 + b;
+   *f = (tmp * r2 + cc) * r2 + d;
+   *df = 2.0 * ((3.0 * tmp - b) * r2 + cc);
+}
+
 /* ---- EAM pass 1 and 3: eam.c:266-419 maths, stencil form of gpu_eam_thread_atom.h:32-140 ---- */
 static void eamPass(const OracleSim* s, Rank* k, int pass)
 {
@@ -491,7 +540,13 @@ static void eamPass(const OracleSim* s, Rank* k, int pass)
             for (int jo = jb * cap, je = jo + k->nAtoms[jb]; jo < je; ++jo) {
                double dx = xi - k->r[0][jo], dy = yi - k->r[1][jo], dz = zi - k->r[2][jo];
                double r2 = dx*dx + dy*dy + dz*dz;
-               if (r2 <= rc2 && r2 > 0.0) {
+               if (r2 <= rc2 && r2 > 0.0 && s->phiSpline) {             /* -P: gpu_eam_thread_atom.h:104-121 */
+                  double phi, dphi, rho, drho;
+                  splineEval(&s->rho, s->rhoSpline, r2, &rho, &drho);
+                  if (pass == 1) { splineEval(&s->phi, s->phiSpline, r2, &phi, &dphi); e += phi; rb += rho; }
+                  else           { dphi = (k->dfE[io] + k->dfE[jo]) * drho; }
+                  fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
+               } else if (r2 <= rc2 && r2 > 0.0) {
                   double r = sqrt(r2), phi, dphi, rho, drho;
                   tableEval(&s->rho, r, &rho, &drho);
                   if (pass == 1) { tableEval(&s->phi, r, &phi, &dphi); e += phi; rb += rho; }
@@ -559,6 +614,15 @@ static void exchangeForce(OracleSim* s)
 }
 
 /* ---- timestep.c:102-105 computeForce -> pot->force ------------------------------------------- */
+void oracle_use_splines(OracleSim* s)
+{
+   if (!s->doeam || s->phiSpline) return;
+   s->phiSpline = splineCoefficients(&s->phi);
+   s->rhoSpline = splineCoefficients(&s->rho);
+   oracle_compute_force(s);
+   oracle_kinetic_energy(s);                      /* also totals the potential energy of the new forces */
+}
+
 void oracle_compute_force(OracleSim* s)
 {
    if (!s->doeam) {
@@ -768,6 +832,7 @@ OracleSim* oracle_create(int nx, int ny, int nz, int px, int py, int pz,
 
 void oracle_destroy(OracleSim* s)
 {
+   if (s) { free(s->phiSpline); free(s->rhoSpline); }
    if (!s) return;
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];

@@ -42,6 +42,9 @@ void oracle_advance_velocity(OracleSim* s, double dt);
 void oracle_advance_position(OracleSim* s, double dt);
 void oracle_redistribute(OracleSim* s);
 void oracle_compute_force(OracleSim* s);
+/* EAM only: switch phi and rho to the reference's GPU-only cubic splines in r^2 (-P) and recompute the forces.  PARITY-UNPINNED:
+ * the reference holds no output of this mode and its CPU path does not implement it. */
+void oracle_use_splines(OracleSim* s);
 void oracle_kinetic_energy(OracleSim* s);
 
 int    oracle_n_global(const OracleSim* s);

@@ -54,6 +54,7 @@ def lib():
     L.oracle_gasdev.restype = cd
     L.oracle_eam_interpolate.argtypes = [vp, ci, cd, ctypes.POINTER(cd), ctypes.POINTER(cd)]
     L.oracle_eam_table.argtypes = [vp, ci, ctypes.POINTER(ci), ctypes.POINTER(cd), ctypes.POINTER(cd), vp]
+    L.oracle_use_splines.argtypes = [vp]
     L.oracle_threads.restype = ci
     L.oracle_set_threads.argtypes = [ci]
     _lib = L
@@ -63,13 +64,15 @@ def lib():
 class Oracle:
     """CPU restatement of the reference path; all ranks of the decomposition live in this process."""
 
-    def __init__(self, n, procs=(1, 1, 1), eam=0, temperature=600.0, delta=0.0, dt=1.0, cap=0, lat=-1.0, pot_name="Cu_u6.eam"):
+    def __init__(self, n, procs=(1, 1, 1), eam=0, temperature=600.0, delta=0.0, dt=1.0, cap=0, lat=-1.0, pot_name="Cu_u6.eam", spline=False):
         self.L = lib()
         nx, ny, nz = (n, n, n) if isinstance(n, int) else n
         self.ptr = self.L.oracle_create(nx, ny, nz, procs[0], procs[1], procs[2], lat, eam,
                                         POT_DIR.encode(), pot_name.encode(), temperature, delta, dt, cap)
         if not self.ptr:
             raise RuntimeError("oracle_create failed")
+        if spline:
+            self.L.oracle_use_splines(self.ptr)          # -P: parity-unpinned restatement of the reference's device code
         self.n_global = self.L.oracle_n_global(self.ptr)
         self.n_ranks = self.L.oracle_n_ranks(self.ptr)
         self.cap = self.L.oracle_rank_cell_cap(self.ptr)

@@ -448,3 +448,24 @@ def test_hilbert_numbering_changes_nothing_but_the_cell_ids(gpu, orc, eam, n, me
     fo = o.gather(orc.F)
     assert np.abs(f1 - fo).max() <= 1e-9 * np.abs(fo).max()
     assert abs((en1[0] + en1[1]) - sum(o.energy())) / en1[2] < TOL["energy_per_atom_trace"]
+
+
+# ---------------------------------------------------------------- cubic-spline EAM tables (-P): PARITY-UNPINNED
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("n,delta", [(8, 0.0), ((7, 9, 12), 0.2)])
+def test_spline_tables_match_the_restatement(gpu, orc, method, n, delta):
+    """-P evaluates phi and rho as cubic splines in r^2 (gpu_utility.c:377-430, gpu_common.h:95-129).  The reference implements this
+    on the GPU only and holds no output of it, so the check is against the oracle's restatement of that device code (parity
+    unpinned) -- plus one sanity bound from the physics: a spline through the same samples stays close to the quadratic tables."""
+    with gpu.Simulation(_args(n, 1, delta, method, ["-P"])) as sim:
+        o = orc.Oracle(n, eam=1, delta=delta, spline=True)
+        fo, eo = o.gather(orc.F), o.gather(orc.U)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
+        assert np.abs(sim.gather(3) - eo).max() <= TOL["per_atom_energy_abs"]
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < 1e-12
+        quad = orc.Oracle(n, eam=1, delta=delta)
+        assert 0 < abs(o.energy()[0] - quad.energy()[0]) / o.n_global < 1e-4          # different interpolant, same potential
+        sim.step(20)
+        o.step(20)
+        (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
+        assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
