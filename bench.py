@@ -54,7 +54,10 @@ def parse():
     ap.add_argument("--async-halo", type=int, default=None, help="-a flag: overlap interior force with the halo exchange")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the other force methods (reported as `variants` at N = 1)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--allow-host-staged", action="store_true",
+                    help="N > 1 only: if the RCCL communicator cannot be formed, run over host-staged gloo messages instead of failing "
+                         "(the line then carries \"measured\": false -- it is a functional rehearsal, not an xGMI number)")
     return ap.parse_args()
 
 
@@ -73,26 +76,35 @@ class stdout_to_stderr:
 
 
 def cpu_baseline(pot, seconds):
-    """Time the oracle on this host: 20^3 cells of the same lattice/potential (BASELINE configs[0] for LJ)."""
+    """Time the oracle on this host: 20^3 cells of the same lattice/potential (BASELINE configs[0] for LJ).
+    Two legs: this GPU's share of the host cores (OpenMP over cells), and ONE core -- the reference is single-threaded
+    per rank ("Threading: none", yamlOutput.c:87), so the 1-core figure is the like-for-like one."""
     orc = ge.load_oracle()
+    lib = orc.lib()
     n = 20
     try:
         cores = len(os.sched_getaffinity(0))
     except AttributeError:
         cores = os.cpu_count() or 1
-    orc.lib().oracle_set_threads(min(cores, 16))        # the GPU box gives one GPU a 16-core share
-    t0 = time.time()
-    o = orc.Oracle(n, eam=1 if pot == "eam" else 0)
-    o.step(2)
-    per_step = max((time.time() - t0) / 3.0, 1e-4)
-    steps = max(5, min(2000, int(seconds / per_step)))
-    lib = orc.lib()
-    before = lib.oracle_loop_seconds(o.ptr)
-    o.step(steps)
-    loop = lib.oracle_loop_seconds(o.ptr) - before
-    rate = o.n_global * steps / loop
-    return {"value": rate, "unit": "atom-updates/s", "cores": int(lib.oracle_threads()), "kind": "port",
-            "sample": f"{pot.upper()} Cu {n}^3 FCC ({o.n_global} atoms), {steps} steps, oracle/comd_oracle.c (27-cell stencil form, OpenMP), {loop:.1f} s"}
+
+    def leg(threads, budget):
+        lib.oracle_set_threads(threads)
+        t0 = time.time()
+        o = orc.Oracle(n, eam=1 if pot == "eam" else 0)
+        o.step(2)
+        per_step = max((time.time() - t0) / 3.0, 1e-4)
+        steps = max(3, min(2000, int(budget / per_step)))
+        before = lib.oracle_loop_seconds(o.ptr)
+        o.step(steps)
+        loop = lib.oracle_loop_seconds(o.ptr) - before
+        return o.n_global * steps / loop, int(lib.oracle_threads()), steps, loop, o.n_global
+
+    rate, used, steps, loop, n_atoms = leg(min(cores, 16), seconds * 0.5)      # the GPU box gives one GPU a 16-core share
+    rate1, _, steps1, loop1, _ = leg(1, seconds * 0.5)
+    return {"value": rate, "unit": "atom-updates/s", "cores": used, "kind": "port",
+            "sample": f"{pot.upper()} Cu {n}^3 FCC ({n_atoms} atoms), {steps} steps, oracle/comd_oracle.c (27-cell stencil form, OpenMP), {loop:.1f} s",
+            "one_core": {"value": rate1, "unit": "atom-updates/s", "cores": 1,
+                         "sample": f"same workload, {steps1} steps, 1 thread (the reference runs one thread per rank), {loop1:.1f} s"}}
 
 
 def measured_traffic(pot, method, nx):
@@ -127,6 +139,7 @@ def main():
     # single rank through RCCL (to itself), with the same library load order and rendezvous as a torch.distributed.run launch.
     loopback = world == 1 and os.environ.get("COMD_LOOPBACK_TRANSPORT", "0") not in ("", "0")
     transport_name = None
+    rccl_info = None
     dist = None
     if world > 1 or loopback:
         import torch.distributed as dist                    # torch first: its bundled HIP/RCCL runtime is the one both sides share
@@ -153,7 +166,24 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks agree on the transport
         if int(flag[0]) == 1:
             pkg.init_parallel(rank, world, transport)
-        else:                                                # no RCCL communicator: host-staged messages over gloo, and say so
+            # what the communicator itself says: N ranks, one device each, and which librccl this process runs
+            n_comm, r_comm, dev = pkg.rccl_comm_info()
+            mine = {"rank": r_comm, "device": dev, "librccl": pkg.mapped_libraries("librccl"), "libamdhip64": pkg.mapped_libraries("libamdhip64")}
+            gathered = [None] * world
+            dist.all_gather_object(gathered, mine)
+            rccl_info = {"rccl_ranks": n_comm, "rank_devices": [g["device"] for g in gathered],
+                         "librccl": sorted({p for g in gathered for p in g["librccl"]}),
+                         "libamdhip64": sorted({p for g in gathered for p in g["libamdhip64"]})}
+            if n_comm != world:
+                sys.exit(f"bench.py: the RCCL communicator reports {n_comm} ranks, launched with {world}")
+        elif not a.allow_host_staged:
+            # a SCALE record must never be produced over host-staged messages by accident
+            if rank == 0:
+                sys.stderr.write("bench.py: the RCCL communicator could not be formed on every rank; refusing to fall back to host-staged "
+                                 "gloo messages (pass --allow-host-staged for a functional rehearsal)\n")
+            dist.barrier()
+            sys.exit(3)
+        else:                                                # explicit opt-in: host-staged messages over gloo, marked as not measured
             transport_name = "gloo-host-staged (RCCL communicator could not be formed)"
             gloo = pkg.GlooTransport(dist)
             pkg.init_parallel(rank, world, gloo.struct)
@@ -175,16 +205,14 @@ def main():
 
         sim.step(warmup)
         sync_all()
-        hip.comdForceTimingEnable(1)
-        hip.comdForceTimingReset()
+        sim.force_timing(True)
         builds0 = sim.nl_builds
         t0 = time.perf_counter()
         sim.step(steps)
         sync_all()
         elapsed = time.perf_counter() - t0
-        n_launch = ctypes.c_int(0)
-        force_ms = hip.comdForceTimingTotalMs(ctypes.byref(n_launch))
-        hip.comdForceTimingEnable(0)
+        force_ms, n_launch = sim.force_timing_total()
+        sim.force_timing(False)
         if dist is not None:
             import torch
             t = torch.tensor([elapsed], dtype=torch.float64)
@@ -193,7 +221,7 @@ def main():
         ep, ek, n_global = sim.energy()
         sim.sum_atoms()
         assert sim.energy()[2] == n_global, "atoms were lost"
-        res = {"elapsed": elapsed, "force_ms": force_ms, "launches": int(n_launch.value), "ep": ep, "ek": ek, "n_global": n_global,
+        res = {"elapsed": elapsed, "force_ms": force_ms, "launches": n_launch, "ep": ep, "ek": ek, "n_global": n_global,
                "cap": sim.max_atoms, "nl_builds": sim.nl_builds - builds0}
         sim.close()
         return res
@@ -233,6 +261,10 @@ def main():
         }
         if method == "thread_atom_nl":
             out["config"]["neighbor_list_builds_timed"] = m["nl_builds"]
+        if rccl_info:
+            out["config"].update(rccl_info)
+        if transport_name:                                  # host-staged rehearsal: not an xGMI measurement
+            out["measured"] = False
     # the other force methods on the same workload (one GPU only): not the headline, reported beside it
     variants = []
     if a.gpus == 1 and not a.no_variants:

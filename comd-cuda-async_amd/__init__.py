@@ -33,6 +33,8 @@ SENDRECV2_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c
 ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 BCAST_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int)
 BARRIER_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p)
+SENDRECV2SIZED_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p)
 
 
 LOAD_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)
@@ -42,7 +44,7 @@ UNLOAD_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_in
 class CommTransport(ctypes.Structure):
     """include/comd_hip.h CommTransport"""
     _fields_ = [("ctx", ctypes.c_void_p), ("sendrecv", SENDRECV_FN), ("sendrecv2", SENDRECV2_FN), ("allreduce", ALLREDUCE_FN),
-                ("bcast", BCAST_FN), ("barrier", BARRIER_FN)]
+                ("bcast", BCAST_FN), ("barrier", BARRIER_FN), ("sendrecv2sized", SENDRECV2SIZED_FN)]
 
 
 _libs = {}
@@ -68,9 +70,12 @@ def lib_hip():
         lib.comdDeviceCount.restype = ctypes.c_int
         lib.comdCommGetUniqueId.argtypes = [ctypes.c_char_p]
         lib.comdCommInitRank.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.POINTER(CommTransport)]
-        lib.comdForceTimingEnable.argtypes = [ctypes.c_int]
-        lib.comdForceTimingTotalMs.argtypes = [c_int_p]
+        lib.comdForceTimingEnable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.comdForceTimingReset.argtypes = [ctypes.c_void_p]
+        lib.comdForceTimingTotalMs.argtypes = [ctypes.c_void_p, c_int_p]
         lib.comdForceTimingTotalMs.restype = ctypes.c_double
+        lib.comdCommInfo.argtypes = [c_int_p, c_int_p, c_int_p]
+        lib.comdCommInfo.restype = ctypes.c_int
         lib.comdEventCreate.restype = ctypes.c_void_p
         lib.comdEventRecord.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.comdEventElapsedMs.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
@@ -95,6 +100,8 @@ def lib_host():
         lib.comdCreateHostOnly.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
         lib.comdMain.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_char_p)]
         lib.comdDestroy.argtypes = [vp]
+        lib.comdSimGpu.argtypes = [vp]
+        lib.comdSimGpu.restype = vp
         lib.comdGetEnergy.argtypes = [vp, c_double_p]
         lib.comdNumGlobal.argtypes = [vp]
         lib.comdNumLocalSlots.argtypes = [vp]
@@ -152,6 +159,25 @@ def rccl_transport(rank, n_ranks, unique_id):
     if rc != 0:
         raise RuntimeError("comdCommInitRank failed")
     return t
+
+
+def rccl_comm_info():
+    """(ranks, my rank, device) as the RCCL communicator itself reports them (ncclCommCount / UserRank / CuDevice)."""
+    n, r, d = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    if lib_hip().comdCommInfo(ctypes.byref(n), ctypes.byref(r), ctypes.byref(d)) != 0:
+        raise RuntimeError("no RCCL communicator")
+    return n.value, r.value, d.value
+
+
+def mapped_libraries(pattern):
+    """Paths of the shared objects mapped into this process whose name contains `pattern` (from /proc/self/maps)."""
+    out = []
+    with open("/proc/self/maps") as f:
+        for line in f:
+            path = line.split()[-1]
+            if pattern in os.path.basename(path) and path not in out:
+                out.append(path)
+    return out
 
 
 def rccl_unique_id():
@@ -215,6 +241,20 @@ class Simulation:
 
     def sum_atoms(self):
         self.lib.sumAtoms(self.ptr)
+
+    # --- device-side timing of the force launches (comd_hip.h comdForceTiming*, per simulation) ---
+    def force_timing(self, on):
+        hip = lib_hip()
+        gpu = ctypes.c_void_p(self.lib.comdSimGpu(self.ptr))
+        hip.comdForceTimingEnable(gpu, 1 if on else 0)
+        if on:
+            hip.comdForceTimingReset(gpu)
+
+    def force_timing_total(self):
+        """(milliseconds, launches) of the force kernels since force_timing(True)."""
+        n = ctypes.c_int(0)
+        ms = lib_hip().comdForceTimingTotalMs(ctypes.c_void_p(self.lib.comdSimGpu(self.ptr)), ctypes.byref(n))
+        return ms, int(n.value)
 
     # --- results ---
     def energy(self):
@@ -306,9 +346,23 @@ class GlooTransport:
         self.dist, self.torch, self.np = dist, torch, np
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.hip = None
-        self._keep = (SENDRECV_FN(self._sendrecv), SENDRECV2_FN(self._sendrecv2), ALLREDUCE_FN(self._allreduce), BCAST_FN(self._bcast),
-                      BARRIER_FN(self._barrier))
+        self.n_sized = 0          # exchanges that went through the pre-agreed-size path (tests look at it)
+        self._keep = (SENDRECV_FN(self._guard(self._sendrecv)), SENDRECV2_FN(self._guard(self._sendrecv2)), ALLREDUCE_FN(self._guard(self._allreduce)),
+                      BCAST_FN(self._guard(self._bcast)), BARRIER_FN(self._guard(self._barrier)), SENDRECV2SIZED_FN(self._guard(self._sendrecv2sized)))
         self.struct = CommTransport(None, *self._keep)
+
+    @staticmethod
+    def _guard(fn):
+        """ctypes swallows exceptions raised inside callbacks (the C caller would carry on with garbage): make them fatal."""
+        def wrapped(*args):
+            try:
+                return fn(*args)
+            except BaseException:
+                import traceback
+                traceback.print_exc()
+                sys.stderr.flush()
+                os._exit(70)
+        return wrapped
 
     def _exchange(self, send_bytes, dest, source, recv_cap):
         torch, dist = self.torch, self.dist
@@ -354,11 +408,53 @@ class GlooTransport:
         n_recv[0] = self._sendrecv(ctx, send_m, n_m, dst_m, recv_p, recv_cap, dst_p, device, stream)
         n_recv[1] = self._sendrecv(ctx, send_p, n_p, dst_p, recv_m, recv_cap, dst_m, device, stream)
 
+    def _sendrecv2sized(self, ctx, send_m, n_m, dst_m, recv_p, n_rp, send_p, n_p, dst_p, recv_m, n_rm, device, stream):
+        """Both ends agree on every size: payloads only, no size messages (the RCCL transport's rcclSendrecv2Sized)."""
+        torch, dist = self.torch, self.dist
+        if not device:
+            raise RuntimeError("sized exchange is a device-buffer path")
+        hip = self.hip or lib_hip()
+        hip.comdStreamSynchronize(ctypes.c_void_p(stream))
+        self.n_sized += 1
+
+        def down(ptr, n):
+            buf = ctypes.create_string_buffer(max(n, 1))
+            if n:
+                hip.comdMemcpyDtoH(buf, ctypes.c_void_p(ptr), ctypes.c_long(n))
+            return torch.frombuffer(bytearray(buf.raw[:max(n, 1)]), dtype=torch.uint8)
+
+        out_m, out_p = down(send_m, n_m), down(send_p, n_p)
+        in_p, in_m = torch.empty(max(n_rp, 1), dtype=torch.uint8), torch.empty(max(n_rm, 1), dtype=torch.uint8)
+        if dst_m == self.rank and dst_p == self.rank:          # loopback
+            assert n_m == n_rp and n_p == n_rm
+            in_p[:n_rp] = out_m[:n_m]
+            in_m[:n_rm] = out_p[:n_p]
+        else:
+            # posting order as in RCCL: minus-face message first -- with dst_m == dst_p the peer's first send meets my first receive
+            reqs = [dist.isend(out_m, dst_m, tag=3), dist.isend(out_p, dst_p, tag=4),
+                    dist.irecv(in_p, dst_p, tag=3), dist.irecv(in_m, dst_m, tag=4)]
+            for r in reqs:
+                r.wait()
+        for ptr, t, n in ((recv_p, in_p, n_rp), (recv_m, in_m, n_rm)):
+            if n:
+                raw = t.numpy()[:n].tobytes()
+                hip.comdMemcpyHtoD(ctypes.c_void_p(ptr), ctypes.create_string_buffer(raw, n), ctypes.c_long(n))
+
     def _allreduce(self, ctx, buf, count, dtype):
         np, torch, dist = self.np, self.torch, self.dist
         ctype = ctypes.c_double if dtype == 1 else ctypes.c_int
         arr = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctype)), shape=(count,))
         t = torch.from_numpy(arr.copy())
+        if dtype == 1 and self.world > 2:
+            # floating-point sums in RANK ORDER (gather, then add 0, 1, 2, ...): the result does not depend on gloo's reduction tree, so
+            # runs are reproducible and comparable bit for bit with a serial sum over the ranks (what the tests' checker does)
+            parts = [torch.empty_like(t) for _ in range(self.world)]
+            dist.all_gather(parts, t)
+            acc = parts[0].clone()
+            for p in parts[1:]:
+                acc += p
+            arr[:] = acc.numpy()
+            return
         dist.all_reduce(t, op=dist.ReduceOp.MAX if dtype == 2 else dist.ReduceOp.SUM)
         arr[:] = t.numpy()
 

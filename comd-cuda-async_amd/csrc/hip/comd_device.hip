@@ -34,43 +34,62 @@ static int g_rank = 0;
 static inline hipStream_t S(comdStream_t s) { return (hipStream_t)s; }
 static inline int ceilDiv(long a, long b) { return (int)((a + b - 1) / b); }
 
-// ---- force-kernel timing (bench.py roofline leg) ---------------------------------------------------------
-static bool g_timing = false;
-static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_evPool;
-static size_t g_evUsed = 0;
-static double g_forceMs = 0.0;
-static int g_forceLaunches = 0;
+// ---- force-kernel timing (bench.py roofline leg): per simulation, SimGpu.timing -----------------------------------
+struct ForceTiming {
+   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+   size_t used = 0;
+   double ms = 0.0;
+   int launches = 0;
+   bool on = false;
+};
 
-static void timingFlush()
+static void timingFlush(ForceTiming* t)
 {
-   for (size_t i = 0; i < g_evUsed; ++i) {
+   if (!t) return;
+   for (size_t i = 0; i < t->used; ++i) {
       float ms = 0.f;
-      HIP_CHECK(hipEventSynchronize(g_evPool[i].second));
-      HIP_CHECK(hipEventElapsedTime(&ms, g_evPool[i].first, g_evPool[i].second));
-      g_forceMs += ms;
+      HIP_CHECK(hipEventSynchronize(t->pool[i].second));
+      HIP_CHECK(hipEventElapsedTime(&ms, t->pool[i].first, t->pool[i].second));
+      t->ms += ms;
    }
-   g_forceLaunches += (int)g_evUsed;
-   g_evUsed = 0;
+   t->launches += (int)t->used;
+   t->used = 0;
 }
 
 struct ForceTimer {
-   hipStream_t st; int idx;
-   explicit ForceTimer(hipStream_t s) : st(s), idx(-1)
+   ForceTiming* t; hipStream_t st; int idx;
+   ForceTimer(SimGpu* sim, hipStream_t s) : t((ForceTiming*)sim->timing), st(s), idx(-1)
    {
-      if (!g_timing) return;
-      if (g_evUsed == g_evPool.size()) {
-         if (g_evPool.size() >= 1024) timingFlush();
-         else { hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); g_evPool.push_back({a, b}); }
+      if (!t || !t->on) return;
+      if (t->used == t->pool.size()) {
+         if (t->pool.size() >= 1024) timingFlush(t);
+         else { hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); t->pool.push_back({a, b}); }
       }
-      idx = (int)g_evUsed++;
-      HIP_CHECK(hipEventRecord(g_evPool[idx].first, st));
+      idx = (int)t->used++;
+      HIP_CHECK(hipEventRecord(t->pool[idx].first, st));
    }
-   ~ForceTimer() { if (idx >= 0) HIP_CHECK(hipEventRecord(g_evPool[idx].second, st)); }
+   ~ForceTimer() { if (idx >= 0) HIP_CHECK(hipEventRecord(t->pool[idx].second, st)); }
 };
 
-extern "C" void comdForceTimingEnable(int on) { g_timing = on != 0; }
-extern "C" void comdForceTimingReset(void) { timingFlush(); g_forceMs = 0.0; g_forceLaunches = 0; }
-extern "C" double comdForceTimingTotalMs(int* nLaunches) { timingFlush(); if (nLaunches) *nLaunches = g_forceLaunches; return g_forceMs; }
+extern "C" void comdForceTimingEnable(SimGpu* sim, int on)
+{
+   if (!sim->timing) { if (!on) return; sim->timing = new ForceTiming(); }
+   ((ForceTiming*)sim->timing)->on = on != 0;
+}
+extern "C" void comdForceTimingReset(SimGpu* sim)
+{
+   ForceTiming* t = (ForceTiming*)sim->timing;
+   if (!t) return;
+   timingFlush(t); t->ms = 0.0; t->launches = 0;
+}
+extern "C" double comdForceTimingTotalMs(SimGpu* sim, int* nLaunches)
+{
+   ForceTiming* t = (ForceTiming*)sim->timing;
+   if (!t) { if (nLaunches) *nLaunches = 0; return 0.0; }
+   timingFlush(t);
+   if (nLaunches) *nLaunches = t->launches;
+   return t->ms;
+}
 
 extern "C" void* comdEventCreate(void) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return (void*)e; }
 extern "C" void comdEventRecord(void* ev, comdStream_t stream) { HIP_CHECK(hipEventRecord((hipEvent_t)ev, S(stream))); }
@@ -82,6 +101,7 @@ extern "C" float comdEventElapsedMs(void* start, void* stop)
    return ms;
 }
 extern "C" void comdEventDestroy(void* ev) { HIP_CHECK(hipEventDestroy((hipEvent_t)ev)); }
+extern "C" void comdEventSynchronize(void* ev) { HIP_CHECK(hipEventSynchronize((hipEvent_t)ev)); }
 
 // ---- device management ---------------------------------------------------------------------------------------
 extern "C" int comdDeviceCount(void)
@@ -115,6 +135,14 @@ extern "C" void comdMemcpyDtoDAsync(void* dst, const void* src, long bytes, comd
 {
    HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, S(stream)));
 }
+
+extern "C" void comdMemcpyAsync(void* dst, const void* src, long bytes, int kind, comdStream_t stream)
+{
+   if (bytes <= 0) return;
+   const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : kind == 3 ? hipMemcpyDeviceToDevice : hipMemcpyHostToHost;
+   HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, k, S(stream)));
+}
+extern "C" void comdDeviceMemset(void* p, int value, long bytes) { if (bytes > 0) HIP_CHECK(hipMemset(p, value, (size_t)bytes)); }
 
 template <typename T> static T* dalloc(size_t n, bool zero = true)
 {
@@ -157,6 +185,7 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
    HIP_CHECK(hipGetDevice(&sim->deviceId));
    sim->rank = cfg->rank; g_rank = cfg->rank;
    sim->maxAtoms = cfg->maxAtoms;
+   sim->needEnergy = 1;
    sim->do_eam = cfg->do_eam;
    sim->mass = cfg->mass;
    if (cfg->maxAtoms < 1 || cfg->maxAtoms > 1024) { fprintf(stderr, "AllocateGpu: maxAtoms %d outside [1,1024]\n", cfg->maxAtoms); exit(-1); }
@@ -314,7 +343,12 @@ extern "C" void updateNAtomsCpu(SimGpu* sim, int* nAtomsHost)
 extern "C" void DestroyGpu(SimGpu* sim)
 {
    HIP_CHECK(hipDeviceSynchronize());
-   timingFlush();
+   if (sim->timing) {
+      ForceTiming* t = (ForceTiming*)sim->timing;
+      timingFlush(t);
+      for (auto& ev : t->pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+      delete t;
+   }
    void* ptrs[] = { sim->boxes.nAtoms, sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
                     sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.e, sim->atoms.iSpecies, sim->atoms.gid,
                     sim->neighbor_cells, sim->species_mass, sim->eam_pot.phi.values, sim->eam_pot.rho.values, sim->eam_pot.f.values,
@@ -347,7 +381,7 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
       if (st[0] & 1) fprintf(stderr, "a link cell overflowed its %d slots (raise --maxAtoms); ", sim->maxAtoms);
       if (st[0] & 2) fprintf(stderr, "a cell stencil holds more atoms than the cta_cell kernel can stage; ");
       if (st[1])     fprintf(stderr, "an atom moved beyond the halo region and was lost; ");
-      if (st[2])     fprintf(stderr, "a halo message overflowed its buffer; ");
+      if (st[2])     fprintf(stderr, "a halo message overflowed its buffer, or grew by more than 12.5 %% + 64 atoms in one step (COMD_HALO_HANDSHAKE=1 exchanges exact sizes); ");
       if (st[3] & 1) fprintf(stderr, "an atom has more neighbours inside the cutoff than the EAM cta_cell pair queue holds (use -m thread_atom); ");
       if (st[3] & 2) fprintf(stderr, "an atom has more than %d neighbours inside cutoff + skin (raise --maxNeighbors); ", sim->atoms.neighborList.maxNeighbors);
       fprintf(stderr, "\n");
@@ -391,14 +425,13 @@ static LjArgs makeLjArgs(SimGpu* sim, int num_cells, int* cells_list)
 
 // Per-atom energies are consumed only by computeEnergy.  The host announces with comdSetEnergyNeeded(0) that the coming
 // force evaluations feed no energy read (all but the last step of a timestep() call); the default is 1 (always compute).
-static int g_needEnergy = 1;
-extern "C" void comdSetEnergyNeeded(int on) { g_needEnergy = on; }
+extern "C" void comdSetEnergyNeeded(SimGpu* sim, int on) { sim->needEnergy = on; }
 
 extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream)
 {
    if (num_cells <= 0) return;
    LjArgs a = makeLjArgs(sim, num_cells, cells_list);
-   ForceTimer timer(S(stream));
+   ForceTimer timer(sim, S(stream));
    if ((method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat) {
       NeighborListGpu* n = &sim->atoms.neighborList;
       (void)nlView(sim);
@@ -411,12 +444,12 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
          HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_nl_slabs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
          attrSet = lds;
       }
-      if (g_needEnergy) hipLaunchKernelGGL(LJ_Force_nl_slabs<true>, dim3(num_cells), dim3(threads), lds, S(stream), a, v, n->maxSlabAtoms);
+      if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_nl_slabs<true>, dim3(num_cells), dim3(threads), lds, S(stream), a, v, n->maxSlabAtoms);
       else              hipLaunchKernelGGL(LJ_Force_nl_slabs<false>, dim3(num_cells), dim3(threads), lds, S(stream), a, v, n->maxSlabAtoms);
    } else if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
       const NlView nl = nlView(sim);
       const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
-      if (g_needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom_nl<true>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
+      if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom_nl<true>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
       else              hipLaunchKernelGGL(LJ_Force_thread_atom_nl<false>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
    } else if (method == CTA_CELL) {
       const size_t lds = ljCtaLdsBytes(sim->maxAtoms);
@@ -439,7 +472,7 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       NeighborListGpu* n = &sim->atoms.neighborList;
       LjPairlist pl; pl.words = n->pairlist; pl.wavesMax = n->pairlistWaves;
       pl.plCut2 = (sim->lj_pot.cutoff + n->skinDistance) * (sim->lj_pot.cutoff + n->skinDistance);
-#define LAUNCH_CTA(PLV) do { if (g_needEnergy) hipLaunchKernelGGL((LJ_Force_cta_cell<PLV, true>), dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl); \
+#define LAUNCH_CTA(PLV) do { if (sim->needEnergy) hipLaunchKernelGGL((LJ_Force_cta_cell<PLV, true>), dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl); \
                             else              hipLaunchKernelGGL((LJ_Force_cta_cell<PLV, false>), dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl); } while (0)
       if (n->slabFormat != 3)                    LAUNCH_CTA(0);
       else if (n->nBuilds == 0) { fprintf(stderr, "ljForceGpu: -L needs buildNeighborListGpu before the first force call\n"); exit(-1); }
@@ -456,7 +489,7 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       { const char* e = getenv("COMD_LJ_WAVES"); if (e && atoi(e) > 0 && atoi(e) < w) w = atoi(e); }
       const int wavesPerBlock = w <= 4 ? w : 4;
       const unsigned nBlocks = w <= 4 ? (unsigned)num_cells : (unsigned)ceilDiv((long)num_cells * w, 4);
-      if (g_needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom<true>, dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w);
+      if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom<true>, dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w);
       else              hipLaunchKernelGGL(LJ_Force_thread_atom<false>, dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w);
    }
    LAUNCH_CHECK();
@@ -483,27 +516,41 @@ static EamArgs makeEamArgs(SimGpu* sim, int num_cells, int* cells_list)
    return a;
 }
 
+// EAM_Force_cta_cell stages `64 / cap` stencil cells per round of 64 lanes and addresses a lane's slot as lane & (cap - 1): the cell
+// capacity must be a power of two of at most 64 (chooseMaxAtoms picks one; --maxAtoms may not)
+static void eamCtaCheckCapacity(const SimGpu* sim)
+{
+   const int cap = sim->maxAtoms;
+   if (cap > 64 || (cap & (cap - 1)) != 0) {
+      fprintf(stderr, "eamForce: -m cta_cell needs a link-cell capacity that is a power of two <= 64 (maxAtoms = %d); use --maxAtoms 16/32/64 or -m thread_atom\n", cap);
+      exit(-1);
+   }
+}
+
 template <int STEP>
 static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int method, hipStream_t st, int spline)
 {
    if (num_cells <= 0) return;
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
-   ForceTimer timer(st);
+   ForceTimer timer(sim, st);
    if (spline) {
       // -P (gpu_kernels.cu:164-226): cubic splines in r^2 for phi and rho, coefficient tables read through L2 (16 KB each for funcfl)
       if (!a.phiS.coefficients || !a.rhoS.coefficients) { fprintf(stderr, "eamForce: spline != 0 but no spline tables were given to AllocateGpu\n"); exit(-1); }
       if (method == CTA_CELL) {
+         eamCtaCheckCapacity(sim);
          const int wide = sim->eam_pot.cutoff > 5.2;          // same stencil-list capacities as the quadratic path (funcfl / setfl cutoffs)
          int grid = ceilDiv(num_cells, EAM_CTA_WAVES);
          if (grid > 2048) grid = 2048;
          if (grid < 8) grid = 8;
          if (!wide) {
             const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, 0);
-            HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            static size_t attrSet = 0;
+            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
             hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
          } else {
             const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
-            HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            static size_t attrSet = 0;
+            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
             hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
          }
       } else if (method == THREAD_ATOM || method == WARP_ATOM) {
@@ -532,6 +579,7 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
       else                         hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
    } else if (method == CTA_CELL) {
+      eamCtaCheckCapacity(sim);
       // funcfl tables (500 samples) live in the LDS; setfl tables (10000 samples, 80 KB each) stay in L2 and the LDS
       // goes to a wider candidate list instead (longer cutoff -> more atoms per stencil)
       const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
@@ -541,13 +589,13 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (grid < 8) grid = 8;                   // the kernel deals cell ranges to XCDs (blockIdx % 8): every XCD needs a workgroup
       if (tablesInLds) {
          const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, tableBytes);
-         static bool attrSet = false;
-         if (!attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = true; }
+         static size_t attrSet = 0;       // the attribute belongs to the device function, i.e. to the process: keyed by the largest size asked for
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
          hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
       } else {
          const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
-         static bool attrSet = false;
-         if (!attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = true; }
+         static size_t attrSet = 0;
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
          hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
       }
    } else {
@@ -564,7 +612,7 @@ extern "C" void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, i
    (void)spline; (void)method;              /* F(rhobar) is quadratic in both modes (gpu_utility.c:443) */
    if (num_cells <= 0) return;
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
-   ForceTimer timer(S(stream));
+   ForceTimer timer(sim, S(stream));
    hipLaunchKernelGGL(EAM_Force_embed, dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, S(stream), a);
    LAUNCH_CHECK();
 }
@@ -670,8 +718,7 @@ extern "C" void sortAtomsGpu(SimGpu* sim, comdStream_t stream)
 
 // ---- halo pack / unpack ------------------------------------------------------------------------------------------------
 // set by comdForceScansReady(1) after scanCellListsGpu has filled every offset array the force exchange will use
-static int g_forceScansReady = 0;
-extern "C" void comdForceScansReady(int on) { g_forceScansReady = on; }
+extern "C" void comdForceScansReady(SimGpu* sim, int on) { sim->forceScansReady = on; }
 
 extern "C" void getAtomMsgSoAPtr(char* buffer, AtomMsgSoA* m, int n)
 {
@@ -696,6 +743,12 @@ extern "C" void comdReadDeviceInt2(const int* d_a, const int* d_b, int out[2], c
    HIP_CHECK(hipMemcpyAsync(&out[0], d_a, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
    HIP_CHECK(hipMemcpyAsync(&out[1], d_b, sizeof(int), hipMemcpyDeviceToHost, S(stream)));
    HIP_CHECK(hipStreamSynchronize(S(stream)));
+}
+
+extern "C" void comdMirrorCounts(const int* d0, const int* d1, const int* d2, const int* d3, int* pinnedDst, comdStream_t stream)
+{
+   hipLaunchKernelGGL(MirrorCounts, dim3(1), dim3(64), 0, S(stream), d0, d1, d2, d3, pinnedDst);
+   LAUNCH_CHECK();
 }
 
 extern "C" int atomMsgCountGpu(SimGpu* sim, const char* msg_d, comdStream_t stream)
@@ -725,16 +778,16 @@ extern "C" void scanCellListsGpu(SimGpu* sim, int nLists, int** d_cellLists, con
 extern "C" void loadForceBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
 {
    hipStream_t st = S(stream);
-   if (!g_forceScansReady) hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
+   if (!sim->forceScansReady) hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
    hipLaunchKernelGGL(LoadForceBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, gpu_buf, d_cellList, d_cellOffsets,
-                      sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
+                      sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms, nCells, sim->msgBoundAtoms, sim->status);
    LAUNCH_CHECK();
 }
 
 extern "C" void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
 {
    hipStream_t st = S(stream);
-   if (!g_forceScansReady) hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
+   if (!sim->forceScansReady) hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
    hipLaunchKernelGGL(UnloadForceBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, gpu_buf, d_cellList, d_cellOffsets,
                       sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
    LAUNCH_CHECK();
@@ -855,10 +908,21 @@ extern "C" int  comm_select_device(int mpiRank) { (void)mpiRank; return 0; }
 extern "C" int  comm_init(...) { return 0; }
 extern "C" void comm_finalize(void) {}
 
+// The comm-layer-only part of the reference's link surface: defined so that its host objects link, never reachable while
+// comm_use_comm() / comm_use_async() answer 0.  A call is a bug in the caller: say which symbol and stop.
+#define COMD_ABSENT(name) extern "C" int name(...) { fprintf(stderr, "%s: the libmp / GPUDirect-Async layer is not part of this build (comm_use_comm() is 0)\n", #name); exit(-1); }
+COMD_ABSENT(comm_irecv) COMD_ABSENT(comm_isend) COMD_ABSENT(comm_isend_on_stream) COMD_ABSENT(comm_send_ready) COMD_ABSENT(comm_send_ready_on_stream)
+COMD_ABSENT(comm_wait_ready_on_stream) COMD_ABSENT(comm_wait_all) COMD_ABSENT(comm_wait_all_on_stream) COMD_ABSENT(comm_flush) COMD_ABSENT(comm_progress)
+COMD_ABSENT(loadAtomsBufferFromGpu_Async) COMD_ABSENT(loadAtomsBufferFromGpu_Comm) COMD_ABSENT(unloadAtomsBufferToGpu_Async) COMD_ABSENT(unloadAtomsBufferToGpu_Comm)
+COMD_ABSENT(loadForceBufferFromGpu_Async) COMD_ABSENT(loadForceBufferFromGpu_Comm) COMD_ABSENT(unloadForceBufferToGpu_Async) COMD_ABSENT(unloadForceBufferToGpu_Comm)
+COMD_ABSENT(unloadForceScanCells) COMD_ABSENT(exchangeDataForceGpu_KI) COMD_ABSENT(neighborListUpdateRequiredGpu_Async)
+#undef COMD_ABSENT
+
 extern "C" void loadPositionBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, const real_t shift[3], SimGpu* sim, comdStream_t stream)
 {
    hipLaunchKernelGGL(LoadPositionBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, S(stream), gpu_buf, d_cellList, d_cellOffsets,
-                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->maxAtoms, shift[0], shift[1], shift[2]);
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->maxAtoms, shift[0], shift[1], shift[2],
+                      nCells, sim->msgBoundAtoms, sim->status);
    LAUNCH_CHECK();
 }
 

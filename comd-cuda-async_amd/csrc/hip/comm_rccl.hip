@@ -3,7 +3,8 @@
 // Takes the place of the reference's comm.cc (libmp / GPUDirect-Async wrappers, :326-657) and of MPI_Sendrecv /
 // MPI_Allreduce in parallel.c:100-193.  One process per GPU; halo messages are device buffers exchanged with
 // ncclSend/ncclRecv pairs on the caller's stream.  Message sizes are data dependent and RCCL has no probe, so each
-// paired exchange first swaps the two byte counts (one int each way) and then the payloads.
+// paired exchange first swaps the two byte counts (one int each way) and then the payloads -- or, when both ends already agree
+// on the sizes (sendrecv2sized: the halo driver's speculative protocol), posts the payloads alone with no host synchronisation.
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <cstdio>
@@ -75,6 +76,22 @@ static void rcclSendrecv2(void*, const void* sendM, int nSendM, int dstM, void* 
    nRecv[0] = nP; nRecv[1] = nM;
 }
 
+// Both ends of every message know its size: the four transfers are enqueued and the host moves on.  With dstM == dstP (a 2-rank axis,
+// e.g. every axis of a 2x2x2 grid) the peer posts its sends in the same order, so its minus-face message meets the first receive
+// (recvP) and its plus-face message the second (recvM): RCCL matches sends and receives between two ranks in posting order.
+static void rcclSendrecv2Sized(void*, const void* sendM, int nSendM, int dstM, void* recvP, int nRecvP, const void* sendP, int nSendP, int dstP,
+                               void* recvM, int nRecvM, int device, comdStream_t stream)
+{
+   hipStream_t st = (hipStream_t)stream;
+   if (!device) { fprintf(stderr, "Rank %d: RCCL transport moves device buffers only\n", g_rank); exit(-1); }
+   NCCLC(ncclGroupStart());
+   if (nSendM > 0) NCCLC(ncclSend(sendM, (size_t)nSendM, ncclChar, dstM, g_comm, st));
+   if (nSendP > 0) NCCLC(ncclSend(sendP, (size_t)nSendP, ncclChar, dstP, g_comm, st));
+   if (nRecvP > 0) NCCLC(ncclRecv(recvP, (size_t)nRecvP, ncclChar, dstP, g_comm, st));
+   if (nRecvM > 0) NCCLC(ncclRecv(recvM, (size_t)nRecvM, ncclChar, dstM, g_comm, st));
+   NCCLC(ncclGroupEnd());
+}
+
 static void rcclAllreduce(void*, void* buf, int count, int dtype)
 {
    const size_t bytes = (size_t)count * (dtype == 1 ? sizeof(double) : sizeof(int));
@@ -126,6 +143,7 @@ extern "C" int comdCommInitRank(const char* id128, int rank, int nRanks, CommTra
    out->ctx = nullptr;
    out->sendrecv = rcclSendrecv;
    out->sendrecv2 = rcclSendrecv2;
+   out->sendrecv2sized = rcclSendrecv2Sized;
    out->allreduce = rcclAllreduce;
    out->bcast = rcclBcast;
    out->barrier = rcclBarrier;
@@ -138,7 +156,12 @@ extern "C" int comdCommInitFromEnv(CommTransport* out, int* rank, int* nRanks, i
    if (!r || !w) return -1;
    *rank = atoi(r); *nRanks = atoi(w); *localRank = l ? atoi(l) : *rank;
    const char* dir = getenv("COMD_RDZV_DIR"); const char* port = getenv("MASTER_PORT"); const char* run = getenv("TORCHELASTIC_RUN_ID");
-   g_idFile = std::string(dir ? dir : "/tmp") + "/comd_rccl_id_" + (port ? port : "29500") + "_" + (run ? run : "0");
+   // One file per LAUNCH: the ranks of a launch share their launcher (torchrun's agent, mpirun, a shell) as parent process, a relaunch
+   // or a later run has another one, and torchrun counts its restarts -- a file left behind by a crashed run is never picked up.
+   // COMD_RDZV_TOKEN overrides the parent pid for launchers that give every rank its own parent.
+   const char* token = getenv("COMD_RDZV_TOKEN"); const char* restart = getenv("TORCHELASTIC_RESTART_COUNT");
+   g_idFile = std::string(dir ? dir : "/tmp") + "/comd_rccl_id_" + (port ? port : "29500") + "_" + (run ? run : "0") + "_" + (restart ? restart : "0") +
+              "_" + (token ? std::string(token) : std::to_string((long)getppid()));
    char id[COMD_UNIQUE_ID_BYTES];
    if (*rank == 0) {
       unlink(g_idFile.c_str());
@@ -162,6 +185,17 @@ extern "C" int comdCommInitFromEnv(CommTransport* out, int* rank, int* nRanks, i
       }
    }
    return comdCommInitRank(id, *rank, *nRanks, out);
+}
+
+extern "C" int comdCommInfo(int* nRanks, int* rank, int* device)
+{
+   if (!g_comm) return -1;
+   int n = 0, r = 0, d = 0;
+   if (ncclCommCount(g_comm, &n) != ncclSuccess || ncclCommUserRank(g_comm, &r) != ncclSuccess || ncclCommCuDevice(g_comm, &d) != ncclSuccess) return -1;
+   if (nRanks) *nRanks = n;
+   if (rank) *rank = r;
+   if (device) *device = d;
+   return 0;
 }
 
 extern "C" void comdCommFinalize(void)

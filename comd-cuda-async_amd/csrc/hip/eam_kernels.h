@@ -278,12 +278,16 @@ void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
             const bool hitA = (r2A <= a.rc2) && (r2A > 0.0) && (c < nCand);
             const bool hitB = twoAtoms && (r2B <= a.rc2) && (r2B > 0.0) && (c < nCand);
             const unsigned long long mA = __ballot(hitA), mB = __ballot(hitB);
-            if (hitA) qA[qnA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u))] = (unsigned short)c;
-            if (hitB) qB[qnB + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u))] = (unsigned short)c;
+            // a store only while the index is inside the queue: an atom with more in-cutoff neighbours than the queue holds loses the excess
+            // (flagged below) instead of overwriting the other queue and the wave's stencil table
+            const int kA = qnA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+            const int kB = qnB + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+            if (hitA && kA < EAM_CTA_QUEUE) qA[kA] = (unsigned short)c;
+            if (hitB && kB < EAM_CTA_QUEUE) qB[kB] = (unsigned short)c;
             qnA += __popcll(mA); qnB += __popcll(mB);
          }
-         // More neighbours inside the cutoff than a queue holds (3x FCC Cu): the excess went into the next queue / past the LDS
-         // allocation (dropped by the hardware); the results are void, the flag makes comdCheckStatus stop the run.
+         // More neighbours inside the cutoff than a queue holds (3x FCC Cu): the excess was dropped above;
+         // the results are void, the flag makes comdCheckStatus stop the run.
          // (reported once, after the cell walk: a store in here costs 4 % -- the loads behind it lose their freedom to move)
          if (qnA > EAM_CTA_QUEUE) { overrun = 1; qnA = EAM_CTA_QUEUE; }
          if (qnB > EAM_CTA_QUEUE) { overrun = 1; qnB = EAM_CTA_QUEUE; }

@@ -182,8 +182,9 @@ void EAM_Force_thread_atom_nl(EamArgs a, NlView nl)
 __global__
 void LoadPositionBuffer(double* __restrict__ buf, const int* __restrict__ list, const int* __restrict__ offsets,
                         const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
-                        const int* __restrict__ nAtoms, int cap, double sx, double sy, double sz)
+                        const int* __restrict__ nAtoms, int cap, double sx, double sy, double sz, int nCells, int boundAtoms, int* __restrict__ status)
 {
+   if (boundAtoms > 0 && offsets[nCells] > boundAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
    const int c = list[blockIdx.x];
    if ((int)threadIdx.x < nAtoms[c]) {
       const size_t s = (size_t)c * cap + threadIdx.x;

@@ -259,6 +259,16 @@ void ScanCellCountsBatch(const int* __restrict__ nAtoms, ScanJobs jobs)
    if (threadIdx.x == 0) out[n] = sCarry;
 }
 
+// four message counts of an axis phase -> pinned host memory (read by the host one step later, behind an event)
+__global__ void MirrorCounts(const int* __restrict__ d0, const int* __restrict__ d1, const int* __restrict__ d2, const int* __restrict__ d3,
+                             int* __restrict__ hostDst)
+{
+   if (threadIdx.x < 4) {
+      const int* src = threadIdx.x == 0 ? d0 : threadIdx.x == 1 ? d1 : threadIdx.x == 2 ? d2 : d3;
+      hostDst[threadIdx.x] = *src;
+   }
+}
+
 // ---- atom halo message -----------------------------------------------------------------------------------
 // gpu_redistribute.h:376-402 LoadAtomsBufferPacked: one workgroup per listed cell gathers its atoms into the SoA
 // message at offsets[cell]; positions are shifted across the periodic boundary.  blockDim.x >= cap.
@@ -322,10 +332,12 @@ void UnloadAtomsBufferPacked(const char* __restrict__ msg, int nBuf, int capacit
 
 // ---- EAM force (dfEmbed) halo message: gpu_redistribute.h:638-672 ---------------------------------------------
 // blockDim.x >= cap; one workgroup per listed cell; positional (both sides hold the cell in gid order).
+// boundAtoms > 0: the size both ends of the message agreed on beforehand; more atoms than that cannot be sent -> status[2]
 __global__
 void LoadForceBuffer(double* __restrict__ buf, const int* __restrict__ list, const int* __restrict__ offsets,
-                     const double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap)
+                     const double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap, int nCells, int boundAtoms, int* __restrict__ status)
 {
+   if (boundAtoms > 0 && offsets[nCells] > boundAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
    const int c = list[blockIdx.x];
    if ((int)threadIdx.x < nAtoms[c]) buf[offsets[blockIdx.x] + threadIdx.x] = dfEmbed[(size_t)c * cap + threadIdx.x];
 }

@@ -2,7 +2,7 @@
  * flags, same defaults, same "Command Line Parameters" YAML block.  Table-driven over getopt_long.
  * Extensions (long options only): --maxAtoms N (link-cell slot capacity; the reference fixes it at
  * compile time with -DMAXATOMS), --maxNeighbors N (Verlet-list rows per atom for the *_nl methods; the reference's
- * MAXNEIGHBORLISTSIZE), --quiet. */
+ * MAXNEIGHBORLISTSIZE), --quiet, --ljCutoffSigmas F (the reference hard-wires 5; 2.5 meets its documented LJ cohesive energy). */
 #include "comd_host.h"
 #include <getopt.h>
 #include <stdlib.h>
@@ -31,6 +31,7 @@ Command parseCommandLine(int argc, char** argv)
    cmd.nx = cmd.ny = cmd.nz = 20;
    cmd.xproc = cmd.yproc = cmd.zproc = 1;
    cmd.nSteps = 100; cmd.printRate = 10;
+   cmd.ljCutoffSigmas = 5.0;
    cmd.dt = 1.0; cmd.lat = -1.0; cmd.temperature = 600.0; cmd.initialDelta = 0.0; cmd.relativeSkinDistance = 0.1;
    int help = 0;
 
@@ -63,6 +64,7 @@ Command parseCommandLine(int argc, char** argv)
       { "maxAtoms",      0,  1, 'i', &cmd.maxAtoms,       0, "link-cell slot capacity (0 = from the lattice)" },
       { "maxNeighbors",  0,  1, 'i', &cmd.maxNeighbors,   0, "neighbour-list rows per atom for *_nl (0 = from cutoff + skin)" },
       { "quiet",         0,  0, 'i', &cmd.quiet,          0, "no stdout report" },
+      { "ljCutoffSigmas", 0, 1, 'd', &cmd.ljCutoffSigmas, 0, "LJ cutoff in sigmas (5 as in ljForce.c:114; 2.5 reproduces the cohesive energy of CoMD.c:897)" },
    };
    const int nDefs = (int)(sizeof defs / sizeof defs[0]);
 

@@ -34,6 +34,7 @@ typedef struct CommandSt {
    int doHilbert, gpuAsync, gpuProfile, ljInterpolation, spline, usePairlist, maxNeighbors;
    int maxAtoms;          /* extension: link-cell slot capacity, 0 = choose from the lattice (reference: -DMAXATOMS) */
    int quiet;             /* extension: suppress the stdout report (library use) */
+   double ljCutoffSigmas; /* extension (tests): LJ cutoff in sigmas; 5 = the reference (ljForce.c:114), 2.5 = upstream CoMD, whose cohesive energy CoMD.c:897 documents */
 } Command;
 
 Command parseCommandLine(int argc, char** argv);
@@ -54,6 +55,9 @@ int  sendReceiveParallel(void* sendBuf, int sendLen, int dest, void* recvBuf, in
 int  sendReceiveDevice(void* sendBuf, int sendLen, int dest, void* recvBuf, int recvLen, int source, comdStream_t stream);
 void sendReceiveDevice2(void* sendM, int nSendM, int dstM, void* recvP, void* sendP, int nSendP, int dstP, void* recvM,
                         int recvCap, comdStream_t stream, int nRecv[2]);
+int  sizedExchangeAvailable(void);
+void sendReceiveDevice2Sized(void* sendM, int nSendM, int dstM, void* recvP, int nRecvP, void* sendP, int nSendP, int dstP, void* recvM, int nRecvM,
+                             comdStream_t stream);
 void addIntParallel(int* sendBuf, int* recvBuf, int count);
 void addRealParallel(real_t* sendBuf, real_t* recvBuf, int count);
 void addDoubleParallel(double* sendBuf, double* recvBuf, int count);
@@ -154,6 +158,16 @@ typedef struct ValidateSt { double eTot0; int nAtoms0; } Validate;
 enum HaloFaceOrder { HALO_X_MINUS, HALO_X_PLUS, HALO_Y_MINUS, HALO_Y_PLUS, HALO_Z_MINUS, HALO_Z_PLUS };
 enum HaloAxisOrder { HALO_X_AXIS, HALO_Y_AXIS, HALO_Z_AXIS };
 
+/* Per axis: the counts (atoms) of the four messages of the previous exchange -- sent through the minus face, sent through the plus face,
+ * received from the plus neighbour, received from the minus neighbour -- mirrored by a one-wave kernel into pinned memory.  Sender and
+ * receiver of a message hold the same number, so both size the next transfer as count + 12.5 % + 64 without talking to each other. */
+typedef struct HaloSpecSt {
+   int   valid;                           /* mirror[] describes the previous exchange of this axis */
+   int   pending;                         /* the mirror kernel has been enqueued: wait for `event` before reading */
+   int*  mirror;                          /* pinned [4] */
+   void* event;
+} HaloSpec;
+
 typedef struct HaloExchangeSt {
    int nbrRank[6];
    int bufCapacity;                       /* bytes per message buffer */
@@ -164,9 +178,18 @@ typedef struct HaloExchangeSt {
    void (*unloadBuffer)(void* parms, void* data, int face, int bufSize, char* buf);
    void (*destroy)(void* parms);
    void* parms;
-   int type;                              /* 0 atoms, 1 force */
+   int type;                              /* 0 atoms, 1 force, 2 positions */
    int deviceBuffers;                     /* 1: the four buffers are device memory */
    char *sendBufM, *sendBufP, *recvBufM, *recvBufP;
+   /* size agreement without a handshake (device buffers, messages that leave the rank) */
+   int msgHeaderBytes, msgBytesPerAtom;   /* bytes of a message of n atoms = msgHeaderBytes + n * msgBytesPerAtom */
+   int capacityAtoms;
+   int exactCounts;                       /* counts cannot change between invalidations (positions between list builds): no slack */
+   /* optional: device addresses of the four counts of axis phase (faceM, faceP), in HaloSpec order */
+   void (*countPtrs)(void* parms, struct HaloExchangeSt* hh, int faceM, int faceP, const int* out[4]);
+   /* optional: tell the plugin the agreed sizes (atoms) of the message it packs for `face` and of the one it unpacks for `face`; 0 = none */
+   void (*setBounds)(void* parms, int face, int sendBoundAtoms, int recvBoundAtoms);
+   HaloSpec spec[3];
 } HaloExchange;
 
 typedef struct AtomExchangeParmsSt {
@@ -176,6 +199,7 @@ typedef struct AtomExchangeParmsSt {
    int* d_cellOffsets;                    /* device scratch, max nCells + 1 */
    real_t shift[6][3];                    /* pbcFactor * globalExtent */
    int capacityAtoms;
+   int sendBound[6], recvBound[6];        /* agreed message sizes in atoms, 0 = none (capacityAtoms applies) */
 } AtomExchangeParms;
 
 typedef struct ForceExchangeParmsSt {
@@ -188,6 +212,7 @@ typedef struct ForceExchangeParmsSt {
    int positions;                         /* 0: dF/drho (1 real per atom); 1: positions + face shift (3 reals per atom) */
    real_t shift[6][3];
    int msgBytesCached[6];                 /* positions: message sizes are fixed between list builds; -1 = unknown */
+   int sendBound[6];                      /* agreed message sizes in atoms, 0 = none */
 } ForceExchangeParms;
 
 HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice);
@@ -196,6 +221,7 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
 HaloExchange* initPositionHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice);
 void preparePositionExchange(HaloExchange* positionExchange, struct SimFlatSt* sim);   /* after every list build */
 void destroyHaloExchange(HaloExchange** haloExchange);
+void invalidateHaloSizes(HaloExchange* haloExchange);      /* the next exchange of every axis swaps exact sizes again */
 void haloExchange(HaloExchange* haloExchange, void* data);
 void exchangeData(HaloExchange* haloExchange, void* data, int iAxis);
 void prepareForceExchange(HaloExchange* forceExchange, struct SimFlatSt* sim);   /* one batched scan of all twelve cell lists */
@@ -281,6 +307,7 @@ int      comdNeighborListBuilds(SimFlat* s);              /* Verlet-list builds 
 void     comdGridInfo(SimFlat* s, int out[6]);            /* gridSize[3], nLocalBoxes, nTotalBoxes, maxAtoms */
 int      comdMain(int argc, char** argv);                /* the reference's main(): CoMD.c:86-187 */
 void     comdDestroy(SimFlat* s);
+SimGpu*  comdSimGpu(SimFlat* s);                          /* the device half, for the comd_hip.h calls that take a SimGpu* (force timing) */
 void     comdGetEnergy(SimFlat* s, double out[3]);       /* ePotential, eKinetic, nGlobal */
 int      comdNumGlobal(SimFlat* s);
 int      comdNumLocalSlots(SimFlat* s);                  /* nTotalBoxes * maxAtoms */

@@ -238,9 +238,9 @@ static int eamForce(SimFlat* s)
    if (!s->gpuProfile) {
       startTimer(eamHaloTimer);
       prepareForceExchange(pot->forceExchange, s);
-      comdForceScansReady(1);
+      comdForceScansReady(g, 1);
       haloExchange(pot->forceExchange, s);
-      comdForceScansReady(0);
+      comdForceScansReady(g, 0);
       stopTimer(eamHaloTimer);
       if (s->gpuAsync) {
          eamForce3GpuAsync(g, s->n_boundary_cells, g->boundary_cells, s->method, g->boundary_stream, s->spline);

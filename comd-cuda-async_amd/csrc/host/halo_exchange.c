@@ -10,6 +10,13 @@
  * periodic neighbour), unloadBuffer runs the unpack kernels.  The reference stages every message through pinned
  * host memory and blocks on six count read-backs per exchange (haloExchange.c:1632-1633, gpu_kernels.cu:534-535).
  * The whole GPUDirect-Async / libmp machinery of haloExchange.c:498-1366 has no counterpart by design.
+ *
+ * Message sizes are data dependent and RCCL cannot probe.  Instead of a size handshake (and the host synchronisations it needs) per
+ * axis phase, both ends of a message derive its transfer size from the count of the SAME message one step earlier, which both hold
+ * (the sender packed it, the receiver unpacked it; a one-wave kernel mirrors the four counts of a phase into pinned memory):
+ * count + 12.5 % + 64 atoms, the true count travels in the message.  The first exchange, the exchanges after a Verlet-list build and
+ * runs with COMD_HALO_HANDSHAKE=1 swap exact sizes instead.  A message that outgrows its agreed size raises the device status flag
+ * (pack and unpack kernels both check) and the run stops at the next status read.
  */
 #include "comd_host.h"
 #include <stdlib.h>
@@ -87,8 +94,9 @@ static int loadAtomsBuffer(void* vparms, void* data, int face, char* buf)
 {
    AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
    SimFlat* sim = (SimFlat*)data;
+   const int bound = parms->sendBound[face] > 0 && parms->sendBound[face] < parms->capacityAtoms ? parms->sendBound[face] : parms->capacityAtoms;
    compactCellsGpu(buf, parms->nCells[face], parms->cellListGpu[face], &sim->gpu, parms->d_cellOffsets,
-                   parms->shift[face], parms->capacityAtoms, sim->gpu.boundary_stream);
+                   parms->shift[face], bound, sim->gpu.boundary_stream);
    return -1;            /* the count stays on the device (message header); exchangeData asks msgBytes only if a peer needs it */
 }
 
@@ -116,9 +124,21 @@ static void unloadAtomsBuffer(void* vparms, void* data, int face, int bufSize, c
 {
    AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
    SimFlat* sim = (SimFlat*)data;
-   (void)face;
    int nBuf = bufSize < 0 ? -1 : (bufSize - COMD_ATOM_MSG_HEADER) / COMD_ATOM_MSG_BYTES_PER_ATOM;
-   unloadAtomsBufferToGpu(buf, nBuf, parms->capacityAtoms, &sim->gpu, sim->gpu.boundary_stream);
+   const int bound = nBuf < 0 && parms->recvBound[face] > 0 && parms->recvBound[face] < parms->capacityAtoms ? parms->recvBound[face] : parms->capacityAtoms;
+   unloadAtomsBufferToGpu(buf, nBuf, bound, &sim->gpu, sim->gpu.boundary_stream);
+}
+
+static void atomsCountPtrs(void* vparms, HaloExchange* hh, int faceM, int faceP, const int* out[4])
+{
+   (void)vparms; (void)faceM; (void)faceP;         /* the counts sit in the message headers */
+   out[0] = (const int*)hh->sendBufM; out[1] = (const int*)hh->sendBufP; out[2] = (const int*)hh->recvBufP; out[3] = (const int*)hh->recvBufM;
+}
+
+static void atomsSetBounds(void* vparms, int face, int sendBoundAtoms, int recvBoundAtoms)
+{
+   AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
+   parms->sendBound[face] = sendBoundAtoms; parms->recvBound[face] = recvBoundAtoms;
 }
 
 static void destroyAtomsExchange(void* vparms)
@@ -153,6 +173,8 @@ HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDev
    hh->type = 0;
    hh->parms = parms;
    hh->deviceBuffers = allocDevice;
+   hh->msgHeaderBytes = COMD_ATOM_MSG_HEADER; hh->msgBytesPerAtom = COMD_ATOM_MSG_BYTES_PER_ATOM; hh->capacityAtoms = parms->capacityAtoms;
+   hh->countPtrs = atomsCountPtrs; hh->setBounds = atomsSetBounds;
    if (allocDevice) {
       for (int f = 0; f < 6; ++f) parms->cellListGpu[f] = uploadInts(parms->cellList[f], parms->nCells[f]);
       parms->d_cellOffsets = (int*)comdDeviceMalloc((long)(2 * maxSize + 1) * sizeof(int));
@@ -167,8 +189,25 @@ static int loadForceBuffer(void* vparms, void* vdata, int face, char* buf)
 {
    ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
    SimFlat* s = (SimFlat*)vdata;
+   s->gpu.msgBoundAtoms = parms->sendBound[face];
    loadForceBufferFromGpu((real_t*)buf, parms->nCells[face], parms->sendCellsGpu[face], parms->sendOffsetsGpu[face], &s->gpu, s->gpu.boundary_stream);
+   s->gpu.msgBoundAtoms = 0;
    return -1;
+}
+
+/* force and position messages: the counts are the totals of the batched scan (send lists: what leaves; receive lists: what must arrive) */
+static void forceCountPtrs(void* vparms, HaloExchange* hh, int faceM, int faceP, const int* out[4])
+{
+   (void)hh;
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   out[0] = parms->sendOffsetsGpu[faceM] + parms->nCells[faceM]; out[1] = parms->sendOffsetsGpu[faceP] + parms->nCells[faceP];
+   out[2] = parms->recvOffsetsGpu[faceP] + parms->nCells[faceP]; out[3] = parms->recvOffsetsGpu[faceM] + parms->nCells[faceM];
+}
+
+static void forceSetBounds(void* vparms, int face, int sendBoundAtoms, int recvBoundAtoms)
+{
+   (void)recvBoundAtoms;                           /* positional unpack: the receive cells know their own occupancy */
+   ((ForceExchangeParms*)vparms)->sendBound[face] = sendBoundAtoms;
 }
 
 static int forceMsgBytes(void* vparms, void* vdata, int face, char* buf)
@@ -233,6 +272,8 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
    hh->type = 1;
    hh->parms = parms;
    hh->deviceBuffers = allocDevice;
+   hh->msgHeaderBytes = 0; hh->msgBytesPerAtom = (int)sizeof(real_t); hh->capacityAtoms = parms->capacityAtoms;
+   hh->countPtrs = forceCountPtrs; hh->setBounds = forceSetBounds;
    if (allocDevice) {
       for (int f = 0; f < 6; ++f) {
          parms->sendCellsGpu[f] = uploadInts(parms->sendCells[f], parms->nCells[f]);
@@ -257,8 +298,10 @@ static int loadPositionBuffer(void* vparms, void* vdata, int face, char* buf)
 {
    ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
    SimFlat* s = (SimFlat*)vdata;
+   s->gpu.msgBoundAtoms = parms->sendBound[face];
    loadPositionBufferFromGpu((real_t*)buf, parms->nCells[face], parms->sendCellsGpu[face], parms->sendOffsetsGpu[face], parms->shift[face],
                              &s->gpu, s->gpu.boundary_stream);
+   s->gpu.msgBoundAtoms = 0;
    return parms->msgBytesCached[face];
 }
 
@@ -312,6 +355,9 @@ HaloExchange* initPositionHaloExchange(Domain* domain, LinkCell* boxes, int allo
    hh->type = 2;
    hh->parms = parms;
    hh->deviceBuffers = allocDevice;
+   hh->msgHeaderBytes = 0; hh->msgBytesPerAtom = 3 * (int)sizeof(real_t); hh->capacityAtoms = parms->capacityAtoms;
+   hh->countPtrs = forceCountPtrs; hh->setBounds = forceSetBounds;
+   hh->exactCounts = 1;                      /* slots are frozen between list builds: the counts of the first exchange hold until the next build */
    if (allocDevice) {
       for (int f = 0; f < 6; ++f) {
          parms->sendCellsGpu[f] = uploadInts(parms->sendCells[f], parms->nCells[f]);
@@ -332,6 +378,7 @@ void preparePositionExchange(HaloExchange* hh, SimFlat* sim)
    ForceExchangeParms* parms = (ForceExchangeParms*)hh->parms;
    prepareForceExchange(hh, sim);
    for (int f = 0; f < 6; ++f) parms->msgBytesCached[f] = -1;
+   invalidateHaloSizes(hh);
 }
 
 void destroyHaloExchange(HaloExchange** pp)
@@ -342,6 +389,10 @@ void destroyHaloExchange(HaloExchange** pp)
    free(hh->parms);
    if (hh->deviceBuffers) {
       comdDeviceFree(hh->sendBufM); comdDeviceFree(hh->sendBufP); comdDeviceFree(hh->recvBufM); comdDeviceFree(hh->recvBufP);
+   }
+   for (int a = 0; a < 3; ++a) {
+      if (hh->spec[a].event) { if (hh->spec[a].pending) comdEventSynchronize(hh->spec[a].event); comdEventDestroy(hh->spec[a].event); }
+      if (hh->spec[a].mirror) comdHostFreePinned(hh->spec[a].mirror);
    }
    free(hh);
    *pp = NULL;
@@ -360,40 +411,87 @@ void prepareForceExchange(HaloExchange* hh, SimFlat* sim)
 }
 
 /* ---- driver -------------------------------------------------------------------------------------------------- */
+void invalidateHaloSizes(HaloExchange* hh) { for (int a = 0; a < 3; ++a) hh->spec[a].valid = 0; }
+
+static int handshakeForced(void)
+{
+   static int cached = -1;
+   if (cached < 0) { const char* e = getenv("COMD_HALO_HANDSHAKE"); cached = e && atoi(e) != 0; }
+   return cached;
+}
+
+/* transfer size both ends derive from last step's count */
+static int boundOf(int last, int capacityAtoms)
+{
+   long b = (long)last + last / 8 + 64;
+   return b > capacityAtoms ? capacityAtoms : (int)b;
+}
+
 void exchangeData(HaloExchange* hh, void* data, int iAxis)
 {
    const int faceM = 2 * iAxis, faceP = faceM + 1;
+   const int nbrM = hh->nbrRank[faceM], nbrP = hh->nbrRank[faceP];
+   const int selfOnly = nbrM == getMyRank() && nbrP == getMyRank() && !loopbackParallel();
+   HaloSpec* sp = &hh->spec[iAxis];
+   const int sized = !selfOnly && hh->deviceBuffers && hh->countPtrs && sizedExchangeAvailable() && !handshakeForced();
+   const int useSized = sized && sp->valid;
+   int bound[4] = { 0, 0, 0, 0 };
+   if (useSized) {
+      if (sp->pending) { comdEventSynchronize(sp->event); sp->pending = 0; }      /* recorded a whole step ago */
+      for (int i = 0; i < 4; ++i) bound[i] = hh->exactCounts ? sp->mirror[i] : boundOf(sp->mirror[i], hh->capacityAtoms);
+      if (hh->setBounds) { hh->setBounds(hh->parms, faceM, bound[0], bound[3]); hh->setBounds(hh->parms, faceP, bound[1], bound[2]); }
+   }
    int nSendM = hh->loadBuffer(hh->parms, data, faceM, hh->sendBufM);
    int nSendP = hh->loadBuffer(hh->parms, data, faceP, hh->sendBufP);
-   const int nbrM = hh->nbrRank[faceM], nbrP = hh->nbrRank[faceP];
 
-   if (nbrM == getMyRank() && nbrP == getMyRank() && !loopbackParallel()) {
+   if (selfOnly) {
       /* this rank is its own neighbour along the axis: what it sends through the minus face arrives through its plus
        * face.  Unpack straight from the send buffers (the reference's comm path has the same shortcut, haloExchange.c:788-853). */
       hh->unloadBuffer(hh->parms, data, faceM, nSendP, hh->sendBufP);
       hh->unloadBuffer(hh->parms, data, faceP, nSendM, hh->sendBufM);
       return;
    }
-   if (nSendM < 0 && nSendP < 0 && hh->msgBytes2) {
-      int n[2];
-      hh->msgBytes2(hh->parms, data, faceM, hh->sendBufM, faceP, hh->sendBufP, n);
-      nSendM = n[0]; nSendP = n[1];
-   }
-   if (nSendM < 0 && hh->msgBytes) nSendM = hh->msgBytes(hh->parms, data, faceM, hh->sendBufM);
-   if (nSendP < 0 && hh->msgBytes) nSendP = hh->msgBytes(hh->parms, data, faceP, hh->sendBufP);
-   int nRecvP, nRecvM;
-   if (hh->deviceBuffers) {
+   if (useSized) {
+      /* sizes agreed beforehand: four transfers enqueued, no size exchange, no host synchronisation; true counts are on the device */
       SimFlat* sim = (SimFlat*)data;
-      int nRecv[2];
-      sendReceiveDevice2(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity,
-                         sim->gpu.boundary_stream, nRecv);
-      nRecvP = nRecv[0]; nRecvM = nRecv[1];
+      const int h = hh->msgHeaderBytes, b = hh->msgBytesPerAtom;
+      sendReceiveDevice2Sized(hh->sendBufM, h + bound[0] * b, nbrM, hh->recvBufP, h + bound[2] * b,
+                              hh->sendBufP, h + bound[1] * b, nbrP, hh->recvBufM, h + bound[3] * b, sim->gpu.boundary_stream);
+      hh->unloadBuffer(hh->parms, data, faceM, -1, hh->recvBufM);
+      hh->unloadBuffer(hh->parms, data, faceP, -1, hh->recvBufP);
+      if (hh->setBounds) { hh->setBounds(hh->parms, faceM, 0, 0); hh->setBounds(hh->parms, faceP, 0, 0); }
    } else {
-      nRecvP = sendReceiveParallel(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->bufCapacity, nbrP);
-      nRecvM = sendReceiveParallel(hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity, nbrM);
+      if (nSendM < 0 && nSendP < 0 && hh->msgBytes2) {
+         int n[2];
+         hh->msgBytes2(hh->parms, data, faceM, hh->sendBufM, faceP, hh->sendBufP, n);
+         nSendM = n[0]; nSendP = n[1];
+      }
+      if (nSendM < 0 && hh->msgBytes) nSendM = hh->msgBytes(hh->parms, data, faceM, hh->sendBufM);
+      if (nSendP < 0 && hh->msgBytes) nSendP = hh->msgBytes(hh->parms, data, faceP, hh->sendBufP);
+      int nRecvP, nRecvM;
+      if (hh->deviceBuffers) {
+         SimFlat* sim = (SimFlat*)data;
+         int nRecv[2];
+         sendReceiveDevice2(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity,
+                            sim->gpu.boundary_stream, nRecv);
+         nRecvP = nRecv[0]; nRecvM = nRecv[1];
+      } else {
+         nRecvP = sendReceiveParallel(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->bufCapacity, nbrP);
+         nRecvM = sendReceiveParallel(hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity, nbrM);
+      }
+      hh->unloadBuffer(hh->parms, data, faceM, nRecvM, hh->recvBufM);
+      hh->unloadBuffer(hh->parms, data, faceP, nRecvP, hh->recvBufP);
    }
-   hh->unloadBuffer(hh->parms, data, faceM, nRecvM, hh->recvBufM);
-   hh->unloadBuffer(hh->parms, data, faceP, nRecvP, hh->recvBufP);
+   if (sized && !(hh->exactCounts && useSized)) {
+      /* leave the four counts of this phase where the next exchange of the axis finds them without asking the device */
+      SimFlat* sim = (SimFlat*)data;
+      const int* p[4];
+      hh->countPtrs(hh->parms, hh, faceM, faceP, p);
+      if (!sp->mirror) { sp->mirror = (int*)comdHostMallocPinned(4 * sizeof(int)); sp->event = comdEventCreate(); }
+      comdMirrorCounts(p[0], p[1], p[2], p[3], sp->mirror, sim->gpu.boundary_stream);
+      comdEventRecord(sp->event, sim->gpu.boundary_stream);
+      sp->pending = 1; sp->valid = 1;
+   }
 }
 
 void haloExchange(HaloExchange* hh, void* data)

@@ -74,6 +74,15 @@ void sendReceiveDevice2(void* sendM, int nSendM, int dstM, void* recvP, void* se
    nRecv[1] = sendReceiveDevice(sendP, nSendP, dstP, recvM, recvCap, dstM, stream);
 }
 
+/* 1 when halo messages leave this rank through a transport that can move pre-agreed sizes without a handshake */
+int sizedExchangeAvailable(void) { return haveTransport && transport.sendrecv2sized != NULL && (nRanks > 1 || loopback); }
+
+void sendReceiveDevice2Sized(void* sendM, int nSendM, int dstM, void* recvP, int nRecvP, void* sendP, int nSendP, int dstP, void* recvM, int nRecvM,
+                             comdStream_t stream)
+{
+   transport.sendrecv2sized(transport.ctx, sendM, nSendM, dstM, recvP, nRecvP, sendP, nSendP, dstP, recvM, nRecvM, 1, stream);
+}
+
 void addIntParallel(int* sendBuf, int* recvBuf, int count)
 {
    memmove(recvBuf, sendBuf, (size_t)count * sizeof(int));

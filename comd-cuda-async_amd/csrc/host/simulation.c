@@ -133,6 +133,7 @@ SimFlat* initSimulationHost(Command cmd)
    sim->useNL = sim->useNL || sim->usePairlist;        /* frozen slots between rebuilds, positional halo refresh */
 
    sim->pot = initPotential(cmd.doeam, cmd.potDir, cmd.potName, cmd.potType);
+   if (!cmd.doeam && cmd.ljCutoffSigmas > 0.0) sim->pot->cutoff = cmd.ljCutoffSigmas * ((LjPotential*)sim->pot)->sigma;
    if (sim->spline) eamUseSplines(sim->pot);
    real_t latticeConstant = cmd.lat;
    if (cmd.lat < 0.0) latticeConstant = sim->pot->lat;
@@ -152,6 +153,15 @@ SimFlat* initSimulationHost(Command cmd)
       int localMax = countFccLattice(cmd.nx, cmd.ny, cmd.nz, latticeConstant, sim->domain, sim->boxes), globalMaxOcc;
       maxIntParallel(&localMax, &globalMaxOcc, 1);
       cap = chooseMaxAtoms(globalMaxOcc, cmd.initialDelta, sim->boxes, cmd.doeam, sim->useNL);
+   }
+   /* EAM_Force_cta_cell stages 64 / cap stencil cells per round and masks slots with cap - 1 (eam_kernels.h): a capacity that is not a
+    * power of two, or exceeds a wave, would hang the staging loop or drop slots without a word.  Refuse it here, before any device work. */
+   if (cmd.doeam && sim->method == CTA_CELL && (cap > 64 || (cap & (cap - 1)) != 0)) {
+      if (printRank())
+         fprintf(stderr, "Error: -e -m cta_cell needs a link-cell capacity that is a power of two <= 64; %s %d.\n"
+                 "       Use --maxAtoms 16, 32 or 64, or -m thread_atom (any capacity).\n",
+                 cmd.maxAtoms > 0 ? "--maxAtoms is" : "this box needs", cap);
+      exit(-1);
    }
    sim->boxes->maxAtoms = cap;
    sim->atoms = initAtoms(sim->boxes);
@@ -478,6 +488,7 @@ int comdPutAtomInBox(SimFlat* s, int gid, int type, const double r[3], const dou
 }
 
 void comdDestroy(SimFlat* s) { destroySimulation(&s); }
+SimGpu* comdSimGpu(SimFlat* s) { return &s->gpu; }
 
 void comdGetEnergy(SimFlat* s, double out[3]) { out[0] = s->ePotential; out[1] = s->eKinetic; out[2] = (double)s->atoms->nGlobal; }
 int comdNumGlobal(SimFlat* s) { return s->atoms->nGlobal; }

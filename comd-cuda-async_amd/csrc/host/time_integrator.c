@@ -19,7 +19,7 @@ double timestep(SimFlat* s, int nSteps, real_t dt)
 
       /* e[] is read by kineticEnergyGpu below only: the last step's forces must carry energies, the others need not
        * (set before redistributeAtoms: with -a 1 it already launches the interior cells' force work) */
-      comdSetEnergyNeeded(ii == nSteps - 1);
+      comdSetEnergyNeeded(&s->gpu, ii == nSteps - 1);
       startTimer(redistributeTimer);
       redistributeAtoms(s);
       stopTimer(redistributeTimer);
@@ -27,7 +27,7 @@ double timestep(SimFlat* s, int nSteps, real_t dt)
       startTimer(computeForceTimer);
       computeForce(s);
       stopTimer(computeForceTimer);
-      comdSetEnergyNeeded(1);
+      comdSetEnergyNeeded(&s->gpu, 1);
 
       startTimer(velocityTimer);
       advanceVelocity(s, 0.5 * dt);
@@ -88,6 +88,9 @@ static void redistributeAtomsNL(SimFlat* sim)
    stopTimer(commReduceTimer);
    sim->interiorLaunched = 0;
    if (needAll) {
+      /* many steps since the last full exchange: the message counts may have drifted past the agreed slack -- swap exact sizes once */
+      invalidateHaloSizes(sim->atomExchange);
+      if (sim->gpu.do_eam) invalidateHaloSizes(((EamPotential*)sim->pot)->forceExchange);
       redistributeAtomsCells(sim, 0);
       startTimer(neighborListBuildTimer);
       buildNeighborListGpu(g, sim->method, 0);

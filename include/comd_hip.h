@@ -107,6 +107,9 @@ typedef struct AtomsGpu {
    NeighborListGpu neighborList;       /* allocated only when GpuConfig.skinDistance > 0 */
 } AtomsGpu;
 
+/* gpu_types.h:38-45: the reference's gid -> slot hash table of its list mode.  Counters only here (atoms keep their slots between builds). */
+typedef struct HashTableGpu { int nMaxEntries, nEntriesPut, nEntriesGet; } HashTableGpu;
+
 /* gpu_types.h:159-190.  Passed by pointer everywhere (the reference passes 856 bytes by value). */
 typedef struct SimGpu {
    int          maxAtoms;              /* slot capacity of a link cell (Makefile:16 MAXATOMS) */
@@ -133,6 +136,15 @@ typedef struct SimGpu {
    real_t*      reduceBuf;             /* device: per-block partial sums for computeEnergy */
    real_t*      pinned;                /* pinned host staging (energies, counts) */
    int          reduceBlocks;
+   /* per-simulation switches of the launch wrappers (library globals in round 1) */
+   int          needEnergy;            /* comdSetEnergyNeeded: 0 = the coming force evaluations feed no energy read */
+   int          forceScansReady;       /* comdForceScansReady: load/unloadForceBuffer*Gpu use the offsets of scanCellListsGpu as they are */
+   int          msgBoundAtoms;         /* > 0: load{Force,Position}BufferFromGpu flag status[2] when the listed cells hold more atoms than this
+                                        * (the size both ends of a halo message agreed on beforehand, see CommTransport.sendrecv2sized) */
+   void*        timing;                /* comdForceTiming*: event pool of this simulation, NULL = off */
+   /* fields the reference's host code assigns (timestep.c:229-236); kept so that those statements compile, not read by the library */
+   HashTableGpu d_hashTable;
+   int          genPairlist;
 } SimGpu;
 
 /* Everything AllocateGpu needs to know about the rank's geometry and potential.
@@ -197,6 +209,9 @@ void  comdHostFreePinned(void* p);
 void  comdMemcpyHtoD(void* dst, const void* src, long bytes);
 void  comdMemcpyDtoH(void* dst, const void* src, long bytes);
 void  comdMemcpyDtoDAsync(void* dst, const void* src, long bytes, comdStream_t stream);
+/* cudaMemcpyAsync / cudaMemset as the reference's host files use them (haloExchange.c:1632, timestep.c:224); kind: 1 H2D, 2 D2H, 3 D2D */
+void  comdMemcpyAsync(void* dst, const void* src, long bytes, int kind, comdStream_t stream);
+void  comdDeviceMemset(void* p, int value, long bytes);
 /* check SimGpu.status; prints and exit(-1)s on cell overflow / lost atoms (DEBUG asserts of gpu_redistribute.h:145-154) */
 void comdCheckStatus(SimGpu* sim, const char* where);
 
@@ -211,7 +226,7 @@ void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, co
 /* The per-atom energy array e[] is read only by computeEnergy.  comdSetEnergyNeeded(0) tells the force wrappers that the
  * next evaluations feed no energy read, so they may skip the energy arithmetic; comdSetEnergyNeeded(1) (the default)
  * restores the reference behaviour of computing e[] on every call.  timestep() brackets all but its last step with it. */
-void comdSetEnergyNeeded(int on);
+void comdSetEnergyNeeded(SimGpu* sim, int on);
 /* eamForce{1,2,3}Gpu(SimGpu, method, spline), gpu_kernels.cu:154-249; spline != 0 needs the spline tables (GpuConfig.phiSpline/rhoSpline)
  * and one of the cell methods (THREAD_ATOM, CTA_CELL) */
 void eamForce1Gpu(SimGpu* sim, int method, int spline);
@@ -283,11 +298,14 @@ void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, 
  * once the atom exchange has been sorted, so all of them can be scanned in ONE launch: scanCellListsGpu fills d_cellOffsets[i]
  * (nCells[i] + 1 ints) for up to 12 lists; comdForceScansReady(1) then tells load/unloadForceBuffer*Gpu to use those offsets as they are. */
 void scanCellListsGpu(SimGpu* sim, int nLists, int** d_cellLists, const int* nCells, int** d_cellOffsets, comdStream_t stream);
-void comdForceScansReady(int on);
+void comdForceScansReady(SimGpu* sim, int on);
 /* blocking read of one device int (message counts for the multi-rank transport) */
 int  comdReadDeviceInt(const int* d_ptr, comdStream_t stream);
 /* two device ints behind ONE stream synchronisation (the two message counts of an axis phase) */
 void comdReadDeviceInt2(const int* d_a, const int* d_b, int out[2], comdStream_t stream);
+/* copy four device ints into pinned host memory (comdHostMallocPinned) from a one-wave kernel on `stream`: no host involvement.
+ * The halo driver mirrors the four message counts of an axis phase this way, records an event behind it and reads them a step later. */
+void comdMirrorCounts(const int* d0, const int* d1, const int* d2, const int* d3, int* pinnedDst, comdStream_t stream);
 
 
 /* ---- inter-rank transport: replaces comm.h:40-74 (libmp/GPUDirect-Async) and parallel.h (MPI) --------------
@@ -308,6 +326,11 @@ typedef struct CommTransportSt {
    void (*allreduce)(void* ctx, void* buf, int count, int dtype /* 0 int sum, 1 double sum, 2 int max */);
    void (*bcast)(void* ctx, void* buf, int len, int root);
    void (*barrier)(void* ctx);
+   /* optional (may be NULL): the same four transfers as sendrecv2 when BOTH ends of every message already agree on its size in bytes
+    * (the halo driver derives the sizes from the counts of the previous step, which sender and receiver both hold; the true count
+    * travels in the message).  No size handshake, no host synchronisation: the transfers are simply enqueued on `stream`. */
+   void (*sendrecv2sized)(void* ctx, const void* sendM, int nSendM, int dstM, void* recvP, int nRecvP, const void* sendP, int nSendP, int dstP,
+                          void* recvM, int nRecvM, int device, comdStream_t stream);
 } CommTransport;
 #define COMD_UNIQUE_ID_BYTES 128
 /* rank 0: create the RCCL unique id (ncclGetUniqueId); the caller distributes the 128 bytes to every rank */
@@ -317,6 +340,8 @@ int  comdCommInitRank(const char* id128, int rank, int nRanks, CommTransport* ou
 /* standalone launcher path: RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT from the environment, id through a file */
 int  comdCommInitFromEnv(CommTransport* out, int* rank, int* nRanks, int* localRank);
 void comdCommFinalize(void);
+/* what the communicator itself reports: ncclCommCount / ncclCommUserRank / ncclCommCuDevice; returns 0, or -1 when there is none */
+int  comdCommInfo(int* nRanks, int* rank, int* device);
 
 /* ---- Verlet neighbour lists (methods thread_atom_nl / warp_atom_nl): gpu_kernels.h:25, 73-78, 87-92 ------------------
  * The reference offers them for EAM only (CoMD.c:291-295 exits for LJ); here both potentials take them. */
@@ -338,7 +363,6 @@ int  pairlistUpdateRequiredGpu(SimGpu* sim);
 void comdPairlistGenerated(SimGpu* sim);
 /* gpu_types.h:38-45 / gpu_kernels.h:71,92: the reference's gid -> slot hash table for its list mode.  Not needed here (atoms keep
  * their slots between list builds); the two entry points only keep the counters, so the reference's call sites link and run. */
-typedef struct HashTableGpu { int nMaxEntries, nEntriesPut, nEntriesGet; } HashTableGpu;
 void initHashTableGpu(HashTableGpu* hashTable, int nMaxEntries);
 void emptyHashTableGpu(HashTableGpu* hashTable);
 /* comm.h:40-74 (libmp / GPUDirect-Async, excluded from this build): "not in use" answers, so that the reference's host code takes its
@@ -352,6 +376,14 @@ int  comm_select_device(int mpiRank);
 int  comm_init();                       /* (MPI_Comm comm, int gpuId) at the reference's call site; returns 0 */
 #endif
 void comm_finalize(void);
+/* The rest of the reference's link surface (the 49 + 3 symbols its host objects leave undefined) exists for the libmp /
+ * GPUDirect-Async layer only and is reachable only when comm_use_comm() / comm_use_async() answer non-zero, which they never do here.
+ * libcomd_hip.so still DEFINES every one of them, so the reference's objects link; calling one prints its name and exit(-1)s:
+ *   comm_irecv comm_isend comm_isend_on_stream comm_send_ready comm_send_ready_on_stream comm_wait_ready_on_stream comm_wait_all
+ *   comm_wait_all_on_stream comm_flush comm_progress
+ *   loadAtomsBufferFromGpu_Async/_Comm unloadAtomsBufferToGpu_Async/_Comm loadForceBufferFromGpu_Async/_Comm
+ *   unloadForceBufferToGpu_Async/_Comm unloadForceScanCells exchangeDataForceGpu_KI neighborListUpdateRequiredGpu_Async
+ * (no prototypes: their reference signatures carry MPI and libmp types; tests/test_boundary_shim.py walks the list) */
 /* Between list builds the halo copies keep their slots and only their positions are refreshed: gather r (+ the periodic shift of
  * the face) of the listed cells, in list order, into gpu_buf (3 real_t per atom); scatter them into the receive cells.  The
  * reference re-sends whole atoms and finds their slots through a gid hash table (haloExchange.c:1622-1700, hashTable.c). */
@@ -364,12 +396,13 @@ void unloadPositionBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellLis
 void*  comdEventCreate(void);
 void   comdEventRecord(void* ev, comdStream_t stream);
 float  comdEventElapsedMs(void* start, void* stop);   /* synchronises on `stop` */
+void   comdEventSynchronize(void* ev);
 void   comdEventDestroy(void* ev);
 /* accumulated device time of the force kernels since the last reset: the library brackets every force launch
  * with events when timing is enabled (off by default; adds two event records per launch). */
-void   comdForceTimingEnable(int on);
-void   comdForceTimingReset(void);
-double comdForceTimingTotalMs(int* nLaunches);
+void   comdForceTimingEnable(SimGpu* sim, int on);
+void   comdForceTimingReset(SimGpu* sim);
+double comdForceTimingTotalMs(SimGpu* sim, int* nLaunches);
 
 #ifdef __cplusplus
 }

@@ -787,6 +787,11 @@ static void rankInit(OracleSim* s, Rank* k, int ir)
    }
 }
 
+/* LJ cutoff in units of sigma for the simulations created from now on.  The reference hard-wires 5 (ljForce.c:114); upstream CoMD's
+ * 2.5 is what its documented LJ cohesive energy (CoMD.c:897) was computed with, so the checker can be run at 2.5 to meet that fixture. */
+static double g_ljCutoffSigmas = 5.0;
+void oracle_set_lj_cutoff_sigmas(double f) { g_ljCutoffSigmas = f > 0.0 ? f : 5.0; }
+
 OracleSim* oracle_create(int nx, int ny, int nz, int px, int py, int pz,
                          double lat, int doeam, const char* potDir, const char* potName,
                          double temperature, double initialDelta, double dt, int cellCap)
@@ -801,7 +806,7 @@ OracleSim* oracle_create(int nx, int ny, int nz, int px, int py, int pz,
       if ((isSetfl ? readSetfl(s, potDir, potName) : readFuncfl(s, potDir, potName)) != 0) { free(s); return NULL; }
    } else {                                        /* ljForce.c:102-120 */
       s->sigma = 2.315; s->epsilon = 0.167; s->mass = 63.55 * kAmuToInternalMass;
-      s->lat = 3.615; s->cutoff = 5 * s->sigma;
+      s->lat = 3.615; s->cutoff = g_ljCutoffSigmas * s->sigma;
    }
    if (lat >= 0.0) s->lat = lat;
    s->cap = cellCap > 0 ? cellCap : (doeam ? 64 : 512);

@@ -33,6 +33,8 @@ enum { ORACLE_R = 0, ORACLE_P = 1, ORACLE_F = 2, ORACLE_U = 3, ORACLE_RHOBAR = 4
 OracleSim* oracle_create(int nx, int ny, int nz, int px, int py, int pz,
                          double lat, int doeam, const char* potDir, const char* potName,
                          double temperature, double initialDelta, double dt, int cellCap);
+/* test-only: LJ cutoff in sigmas for the simulations created afterwards (default 5 = ljForce.c:114; 2.5 meets CoMD.c:897) */
+void oracle_set_lj_cutoff_sigmas(double f);
 void oracle_destroy(OracleSim* s);
 
 /* timestep() of timestep.c:48-100: nSteps velocity-Verlet steps, then kinetic energy. */

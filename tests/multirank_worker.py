@@ -98,7 +98,7 @@ def host_mode(pkg, orc, transport, rank, world, grid, eam, n):
     print(f"rank {rank}: host-mode OK ({sum(nat[:nl])} local atoms, {sum(nat[nl:])} halo atoms)")
 
 
-def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async):
+def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async, transport=None):
     import torch
     pkg.setup_gpu(0, rank)
     hilbert = method.endswith("+H")                          # "+H": Hilbert numbering of the link cells on every rank
@@ -145,7 +145,8 @@ def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async):
         assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < 2e-12
         if method.endswith("_nl"):
             assert 1 < sim.nl_builds < steps, sim.nl_builds
-        print(f"gpu-mode OK: {world} ranks {grid}, {'EAM' if eam else 'LJ'} {n}^3 {method} async={use_async}: E/atom {(e1[0]+e1[1])/e1[2]:.12f}")
+        print(f"gpu-mode OK: {world} ranks {grid}, {'EAM' if eam else 'LJ'} {n}^3 {method} async={use_async}: E/atom {(e1[0]+e1[1])/e1[2]:.12f}, "
+              f"{transport.n_sized if transport else 0} sized exchanges")
     sim.close()
 
 
@@ -157,12 +158,16 @@ def rccl_loopback_mode(pkg, orc, eam, n, method, use_async):
     pkg.init_parallel(0, 1, t)
     assert pkg.lib_host().loopbackParallel() == 1
     args = ["-x", n, "-y", n, "-z", n, "-r", 0.1, "-m", method, "-a", use_async] + (["-e"] if eam else [])
+    steps = 12
+    if method.endswith("_nl") and not eam:
+        args += ["-S", 0.03]                                 # LJ lists: a skin short enough for rebuilds (and size re-handshakes) inside the run
+        steps = 40
     sim = pkg.Simulation(args)
     o = orc.Oracle(n, eam=eam, delta=0.1)
     fo = o.gather(orc.F)
     assert np.abs(sim.gather(2) - fo).max() < 1e-11 * np.abs(fo).max()
-    sim.step(12)
-    o.step(12)
+    sim.step(steps)
+    o.step(steps)
     e1, eo, fo = sim.energy(), o.energy(), o.gather(orc.F)
     assert np.abs(sim.gather(2) - fo).max() < 1e-9 * np.abs(fo).max()
     assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < 2e-12
@@ -192,7 +197,7 @@ def main():
     if mode == "host":
         host_mode(pkg, orc, transport, rank, world, grid, eam, n)
     else:
-        gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async)
+        gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async, transport)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -57,6 +57,7 @@ def lib():
     L.oracle_use_splines.argtypes = [vp]
     L.oracle_threads.restype = ci
     L.oracle_set_threads.argtypes = [ci]
+    L.oracle_set_lj_cutoff_sigmas.argtypes = [cd]
     _lib = L
     return L
 
@@ -64,11 +65,14 @@ def lib():
 class Oracle:
     """CPU restatement of the reference path; all ranks of the decomposition live in this process."""
 
-    def __init__(self, n, procs=(1, 1, 1), eam=0, temperature=600.0, delta=0.0, dt=1.0, cap=0, lat=-1.0, pot_name="Cu_u6.eam", spline=False):
+    def __init__(self, n, procs=(1, 1, 1), eam=0, temperature=600.0, delta=0.0, dt=1.0, cap=0, lat=-1.0, pot_name="Cu_u6.eam", spline=False,
+                 lj_cutoff_sigmas=5.0):
         self.L = lib()
         nx, ny, nz = (n, n, n) if isinstance(n, int) else n
+        self.L.oracle_set_lj_cutoff_sigmas(lj_cutoff_sigmas)       # 5 = the reference (ljForce.c:114); 2.5 meets the fixture of CoMD.c:897
         self.ptr = self.L.oracle_create(nx, ny, nz, procs[0], procs[1], procs[2], lat, eam,
                                         POT_DIR.encode(), pot_name.encode(), temperature, delta, dt, cap)
+        self.L.oracle_set_lj_cutoff_sigmas(5.0)
         if not self.ptr:
             raise RuntimeError("oracle_create failed")
         if spline:

@@ -114,6 +114,27 @@ def test_eam_cohesive_energy(gpu):
         assert abs(_per_atom(sim)[1] - G["repo_native"]["eam_adams_cohesive_energy"]["value"]) < TOL["energy_per_atom_step0"]
 
 
+@pytest.mark.parametrize("method,extra", [("thread_atom", ()), ("cta_cell", ()), ("thread_atom_nl", ()), ("cta_cell", ("-L",))])
+def test_lj_cohesive_energy(gpu, orc, method, extra):
+    """CoMD.c:897: the reference's documented LJ cohesive energy, -1.243619295058 eV/atom (cutoff 2.5 sigma, see
+    tests/test_oracle_golden.py::test_lj_cohesive_energy_repo_native).  Every LJ kernel at --ljCutoffSigmas 2.5: the fixture to 1e-10,
+    the oracle at the same cutoff to the usual tolerances, with and without displacements (forces are zero on the perfect lattice)."""
+    ref = G["repo_native"]["lj_cohesive_energy_2p5_sigma"]
+    with gpu.Simulation(_args(10, 0, 0.0, method, ["-T", 0, "--ljCutoffSigmas", 2.5, *extra])) as sim:
+        _, u, k = _per_atom(sim)
+        assert k == 0.0 and abs(u - ref["value"]) < ref["tolerance"]
+        assert np.abs(sim.gather(2)).max() < 1e-11
+    with gpu.Simulation(_args(10, 0, 0.15, method, ["--ljCutoffSigmas", 2.5, *extra])) as sim:
+        o = orc.Oracle(10, eam=0, delta=0.15, lj_cutoff_sigmas=2.5)
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * np.abs(fo).max()
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+        sim.step(10)
+        o.step(10)
+        (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
+        assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
+
+
 # ---------------------------------------------------------------- Verlet neighbour lists (-m thread_atom_nl)
 @pytest.mark.parametrize("eam,n,delta", [(0, 12, 0.0), (0, (11, 13, 12), 0.2), (1, 8, 0.1), (1, (7, 9, 12), 0.3)])
 def test_neighbor_list_forces_match_oracle(gpu, orc, eam, n, delta):

@@ -93,12 +93,24 @@ def test_capacity_rule(pkg):
         assert s.max_atoms == 192
 
 
+@pytest.mark.parametrize("cap", [48, 128])
+def test_eam_cta_cell_refuses_capacities_it_cannot_stage(cap):
+    """EAM_Force_cta_cell addresses slots as lane & (cap - 1) and stages 64 / cap cells per round: --maxAtoms 48 would silently drop slots,
+    128 would never advance the staging loop.  The host refuses both before touching the device; thread_atom takes any capacity."""
+    code = ("import sys; sys.path.insert(0, %r); import __graft_entry__ as ge; pkg = ge.load_package(); pkg.init_parallel(0, 1, None); "
+            "pkg.Simulation(['-x', 8, '-y', 8, '-z', 8, '-e', '-m', sys.argv[1], '--maxAtoms', %d], host_only=True); print('created')" % (ROOT, cap))
+    bad = subprocess.run([os.sys.executable, "-c", code, "cta_cell"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "power of two" in bad.stderr and "created" not in bad.stdout
+    ok = subprocess.run([os.sys.executable, "-c", code, "thread_atom"], capture_output=True, text=True)
+    assert ok.returncode == 0 and "created" in ok.stdout, ok.stderr
+
+
 def test_abi_exports_every_declared_symbol(pkg):
     """libcomd_hip.so exports every function include/comd_hip.h declares (load only; no device calls)."""
     header = open(os.path.join(ROOT, "include", "comd_hip.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     names = set(re.findall(r"^\s*(?:const\s+)?[A-Za-z_][\w\s\*]*?\b(\w+)\s*\([^;{]*\)\s*;", header, flags=re.M))
-    names -= {"sendrecv", "allreduce", "bcast", "barrier"}
+    names -= {"sendrecv", "sendrecv2", "sendrecv2sized", "allreduce", "bcast", "barrier"}
     assert {"ljForceGpu", "eamForce1Gpu", "eamForce2Gpu", "eamForce3Gpu", "advanceVelocityGpu", "advancePositionGpu",
             "computeEnergy", "updateLinkCellsGpu", "buildAtomListGpu", "sortAtomsGpu", "compactCellsGpu",
             "unloadAtomsBufferToGpu", "loadForceBufferFromGpu", "unloadForceBufferToGpu", "getAtomMsgSoAPtr",

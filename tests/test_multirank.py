@@ -48,6 +48,15 @@ def test_host_logic_two_processes_gloo(grid, eam, n):
     assert all("host-mode OK" in o for o in outs)
 
 
+@pytest.mark.parametrize("eam,n", [(1, 12), (0, 22)])
+def test_host_logic_2x2x2_eight_processes_gloo(eam, n):
+    """BASELINE configs 4/5 run on a 2x2x2 rank grid: on every axis the minus and the plus neighbour are the SAME peer
+    (decomposition.c:57-66), so both messages of an axis phase travel between one pair of ranks and must not be swapped.
+    Eight real processes, bit-exact against the oracle's eight virtual ranks (EAM 12^3 and LJ 22^3)."""
+    outs = _launch("host", (2, 2, 2), eam, n, timeout=900)
+    assert all("host-mode OK" in o for o in outs)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("grid,eam,n,method,use_async", [((2, 1, 1), 1, 10, "cta_cell", 0), ((2, 2, 1), 1, 12, "thread_atom", 1),
                                                            ((1, 2, 1), 0, 14, "thread_atom", 0), ((2, 1, 2), 0, 20, "cta_cell", 1),
@@ -59,10 +68,19 @@ def test_host_logic_two_processes_gloo(grid, eam, n):
 def test_gpu_path_multi_rank_shared_device(grid, eam, n, method, use_async):
     outs = _launch("gpu", grid, eam, n, extra=(method, use_async))
     assert "gpu-mode OK" in outs[0]
+    assert "sized exchanges" in outs[0] and " 0 sized exchanges" not in outs[0]      # the no-handshake protocol carried the run
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("eam,n,method,use_async", [(0, 14, "thread_atom", 0), (1, 10, "cta_cell", 1), (1, 10, "thread_atom_nl", 1)])
+@pytest.mark.parametrize("grid,eam,n,method,use_async", [((2, 1, 1), 1, 10, "cta_cell", 1), ((1, 2, 1), 0, 14, "thread_atom", 0)])
+def test_gpu_path_multi_rank_exact_size_handshake(grid, eam, n, method, use_async):
+    """COMD_HALO_HANDSHAKE=1: the exact-size handshake of round 1 (what the first exchange and the post-rebuild exchanges still use)."""
+    outs = _launch("gpu", grid, eam, n, extra=(method, use_async), env_extra={"COMD_HALO_HANDSHAKE": "1"})
+    assert "gpu-mode OK" in outs[0] and " 0 sized exchanges" in outs[0]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("eam,n,method,use_async", [(0, 14, "thread_atom", 0), (1, 10, "cta_cell", 1), (1, 10, "thread_atom_nl", 1), (0, 22, "thread_atom_nl", 0)])
 def test_rccl_transport_loopback(eam, n, method, use_async):
     """comm_rccl.hip on real hardware: a one-rank RCCL communicator carries all six halo messages per exchange (size handshake +
     grouped ncclSend/ncclRecv to itself), the EAM dF/drho exchange and the energy / atom-count reductions."""

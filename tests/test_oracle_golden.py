@@ -27,6 +27,21 @@ def test_eam_cohesive_energy_repo_native(orc):
     assert abs(u - G["repo_native"]["eam_adams_cohesive_energy"]["value"]) < TOL["energy_per_atom_step0"]
 
 
+def test_lj_cohesive_energy_repo_native(orc):
+    """CoMD.c:897: the documented LJ cohesive energy, -1.243619295058 eV/atom, is the perfect-lattice sum at a cutoff of 2.5 sigma
+    (upstream CoMD's; this fork's ljForce.c:114 uses 5 sigma with the same pair formula and shift rule).  The checker run at 2.5 sigma
+    meets it to 2e-11 (the printed value carries 12 decimals; an independent lattice sum gives -1.24361929508); stated tolerance 1e-10."""
+    ref = G["repo_native"]["lj_cohesive_energy_2p5_sigma"]
+    o = orc.Oracle(10, eam=0, temperature=0.0, lj_cutoff_sigmas=2.5)
+    _, u, k = per_atom(o)
+    assert k == 0.0
+    assert abs(u - ref["value"]) < ref["tolerance"]
+    assert np.abs(o.gather(orc.F)).max() < 1e-12                  # perfect lattice: every force is a sum that cancels
+    # and on 2x2x2 virtual ranks (decomposition independence at the shorter cutoff too)
+    o8 = orc.Oracle(12, (2, 2, 2), eam=0, temperature=0.0, lj_cutoff_sigmas=2.5)
+    assert abs(per_atom(o8)[1] - ref["value"]) < ref["tolerance"]
+
+
 def test_eam_step0_row_of_k20_log(orc):
     """Step-0 row of out16_80_3.txt: U and K per atom do not depend on the lattice size for a perfect lattice at exactly 600 K."""
     ref = G["repo_native"]["eam_80_step0_gpu_log"]
