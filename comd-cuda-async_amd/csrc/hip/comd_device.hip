@@ -384,7 +384,6 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
       if (st[2])     fprintf(stderr, "a halo message overflowed its buffer, or grew by more than 12.5 %% + 64 atoms in one step (COMD_HALO_HANDSHAKE=1 exchanges exact sizes); ");
       if (st[3] & 1) fprintf(stderr, "an atom has more neighbours inside the cutoff than the EAM cta_cell pair queue holds (use -m thread_atom); ");
       if (st[3] & 2) fprintf(stderr, "an atom has more than %d neighbours inside cutoff + skin (raise --maxNeighbors); ", sim->atoms.neighborList.maxNeighbors);
-      if (st[3] & 4) fprintf(stderr, "an atom has more than %d in-cutoff neighbours inside one group of 9 stencil cells (LJ tile kernel; COMD_LJ_KERNEL=classic has no such limit); ", LJT_QCAP);
       fprintf(stderr, "\n");
       exit(-1);
    }
@@ -428,17 +427,6 @@ static LjArgs makeLjArgs(SimGpu* sim, int num_cells, int* cells_list)
 // force evaluations feed no energy read (all but the last step of a timestep() call); the default is 1 (always compute).
 extern "C" void comdSetEnergyNeeded(SimGpu* sim, int on) { sim->needEnergy = on; }
 
-// Which kernel serves the cell methods: COMD_LJ_KERNEL=tiles (LJ_Force_cell_tiles) or classic (LJ_Force_thread_atom / LJ_Force_cta_cell).
-// Pairlists (-L) are a feature of the classic cta_cell kernel.
-static bool ljUseTiles(const SimGpu* sim, int method)
-{
-   if (method != THREAD_ATOM && method != WARP_ATOM && method != CTA_CELL) return false;
-   if (sim->atoms.neighborList.slabFormat == 3) return false;
-   static int mode = -1;
-   if (mode < 0) { const char* e = getenv("COMD_LJ_KERNEL"); mode = e && !strcmp(e, "tiles") ? 1 : 0; }
-   return mode == 1;
-}
-
 extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream)
 {
    if (num_cells <= 0) return;
@@ -463,30 +451,6 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
       if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom_nl<true>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
       else              hipLaunchKernelGGL(LJ_Force_thread_atom_nl<false>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
-   } else if (ljUseTiles(sim, method)) {
-      // CTA per cell, wave per atom pair, lanes = candidates (lj_kernels.h LJ_Force_cell_tiles)
-      int occ = sim->max_atoms_cell > 0 ? sim->max_atoms_cell + 32 : sim->maxAtoms;      // what the host last saw + slack; unknown: the capacity
-      if (occ > sim->maxAtoms) occ = sim->maxAtoms;
-      LjTileGeom geo;
-      geo.tilesPerCell = (occ + 31) / 32;
-      // fp32 slack of the tile-box test: coordinates up to maxAbs carry <= 2 ulp(maxAbs) per component after the outward rounding
-      double maxAbs = 0.0;
-      for (int ax = 0; ax < 3; ++ax) {
-         const double w = 1.0 / sim->boxes.invBoxSize[ax];
-         maxAbs = fmax(maxAbs, fmax(fabs(sim->boxes.localMin[ax] - w), fabs(sim->boxes.localMax[ax] + w)));
-      }
-      const double rcP = sim->lj_pot.cutoff + 16.0 * 1.2e-7 * maxAbs + 1.0e-6;
-      geo.rcPrune2 = (float)(rcP * rcP * (1.0 + 1.0e-6));
-      const size_t lds = ljTileLdsBytes(geo.tilesPerCell);
-      if (lds > 160 * 1024) { fprintf(stderr, "ljForceGpu: %d atoms per cell do not fit the tile kernel's LDS\n", occ); exit(-1); }
-      static size_t attrSet = 0;
-      if (lds > attrSet) {
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cell_tiles<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cell_tiles<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         attrSet = lds;
-      }
-      if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_cell_tiles<true>, dim3(num_cells), dim3(LJT_THREADS), lds, S(stream), a, geo, sim->status);
-      else                 hipLaunchKernelGGL(LJ_Force_cell_tiles<false>, dim3(num_cells), dim3(LJT_THREADS), lds, S(stream), a, geo, sim->status);
    } else if (method == CTA_CELL) {
       const size_t lds = ljCtaLdsBytes(sim->maxAtoms);
       static size_t attrSet = 0;

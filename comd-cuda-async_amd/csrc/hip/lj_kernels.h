@@ -298,192 +298,3 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
          if (ENERGY) a.e[io] = e[u] * 2.0 * a.eps;
       }
 }
-
-// ===================================================================================================================
-// LJ_Force_cell_tiles: CTA per link cell, WAVE per atom pair, lanes = candidates.
-//
-// Why: with a thread per atom (kernels above) the neighbour j is tested by 64 atoms at once and the pair evaluation is issued whenever
-// ANY of them is inside the cutoff -- for 5-sigma LJ that is every second candidate, with 14 % of the lanes doing useful work
-// (profiles/r01_summary.md).  Here the roles are swapped.  The workgroup stages the stencil, one group of 9 cells at a time, in the
-// LDS as {x,y,z} records in TILES of 32 (each stencil cell padded to whole tiles), with the bounding box of every tile.  A wave
-// takes two atoms A, B of the cell at a time (lanes 0-31 work for A, 32-63 for B):
-//   1. prune : lane = tile; distance from A / B to the tile's box -> 64-bit mask of tiles worth visiting (about half of them);
-//   2. test  : per visited tile 32 candidates x 2 atoms, exact fp64 r^2; hits are compacted (ballot + mbcnt) into one 16-bit
-//              LDS queue per atom -- the in-cutoff neighbours of the atom, nothing else;
-//   3. force : the queues are evaluated 64 pairs per atom and trip at full lane occupancy (positions gathered from the LDS records);
-//   4. sum   : v_permlane32_swap + DPP fold the two atoms' lane partials (pairSum), lane 31 / 63 add them to the cell's LDS accumulators.
-// Per atom: ~34 tile visits x 32 tests instead of 4000 tests, 554 evaluations in 9 full trips instead of ~2000 mostly empty ones.
-// Deterministic: tile order, lane order and the reduction tree are fixed, so runs stay bit-reproducible.
-#define LJT_WAVES   8
-#define LJT_THREADS (64 * LJT_WAVES)
-#define LJT_QCAP    448                 // in-cutoff neighbours of ONE atom inside ONE group of 9 stencil cells (FCC Cu, 5 sigma: ~185 +- 60)
-#define LJT_GROUP_CELLS 9
-
-__device__ __forceinline__ int ljtGroupCell(int g, int kk)
-{
-   // the classes of (dx + dy + dz) mod 3 of the stencil offsets, as indices into the self-first neighbour table: every class mixes near
-   // and far cells, so an atom finds a similar share of its neighbours in each (queue capacity, balance between the groups)
-   constexpr unsigned char tab[3][9] = { { 1, 6, 8, 12, 0, 15, 19, 21, 26 }, { 2, 4, 9, 10, 14, 16, 20, 22, 24 }, { 3, 5, 7, 11, 13, 17, 18, 23, 25 } };
-   return tab[g][kk];
-}
-
-struct LjTileGeom { int tilesPerCell; float rcPrune2; };      // tiles a stencil cell may occupy; pruning radius^2 with the fp32 slack
-
-static inline size_t ljTileLdsBytes(int tilesPerCell)
-{
-   const size_t maxTiles = (size_t)LJT_GROUP_CELLS * tilesPerCell;
-   return maxTiles * 32 * 3 * sizeof(double)                 // records
-        + (size_t)tilesPerCell * 32 * 4 * sizeof(double)     // accumulators of the cell's own atoms
-        + 6 * ((maxTiles + 63) & ~(size_t)63) * sizeof(float)   // tile boxes
-        + (size_t)LJT_WAVES * 2 * LJT_QCAP * sizeof(unsigned short);
-}
-
-template <bool ENERGY>
-__global__ __launch_bounds__(LJT_THREADS)
-void LJ_Force_cell_tiles(LjArgs a, LjTileGeom geo, int* __restrict__ status)
-{
-   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-   const int maxTiles = LJT_GROUP_CELLS * geo.tilesPerCell;
-   const int tbStride = (maxTiles + 63) & ~63;
-   double* __restrict__ recs = (double*)ldsRaw;                                   // [maxTiles * 32][3]
-   double* __restrict__ acc = recs + (size_t)maxTiles * 32 * 3;                  // [tilesPerCell * 32][4]
-   float* __restrict__ tb = (float*)(acc + (size_t)geo.tilesPerCell * 32 * 4);  // [6][tbStride]: min x,y,z, max x,y,z
-   unsigned short* __restrict__ qAll = (unsigned short*)(tb + 6 * tbStride);
-
-   const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5;
-   const int wave = uniform(threadIdx.x >> 6);
-   unsigned short* __restrict__ q = qAll + (size_t)wave * 2 * LJT_QCAP;         // [2][LJT_QCAP]
-
-   const int ci = xcdRemap(blockIdx.x, gridDim.x);
-   const int iBox = uniform(a.cells ? a.cells[ci] : ci);
-   int ni = uniform(a.nAtoms[iBox]);
-   if (ni == 0) return;                                                          // workgroup-uniform
-   const int slotsPerCell = geo.tilesPerCell * 32;
-   bool tooMany = ni > slotsPerCell, qOver = false;
-   if (tooMany) ni = slotsPerCell;
-   for (int t = threadIdx.x; t < slotsPerCell * 4; t += LJT_THREADS) acc[t] = 0.0;
-   const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
-
-   for (int g = 0; g < 3; ++g) {
-      __syncthreads();                                       // the previous group's records are no longer read (and acc is zeroed)
-      // ---- stage group g: every wave works out the tile layout for itself (lanes 0..8 = the 9 cells), tiles are dealt to the waves in pairs
-      int cBox = 0, cN = 0, cT0 = 0;
-      if (lane < LJT_GROUP_CELLS) { cBox = nb[ljtGroupCell(g, lane)]; cN = a.nAtoms[cBox]; }
-      if (cN > slotsPerCell) { tooMany = true; cN = slotsPerCell; }
-      const int cT = (cN + 31) >> 5;
-      {
-         int incl = cT;
-#pragma unroll
-         for (int d = 1; d < 16; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-         cT0 = incl - cT;
-      }
-      const int nTiles = uniform(__shfl(cT0 + cT, LJT_GROUP_CELLS - 1));
-      for (int tp = wave; 2 * tp < nTiles; tp += LJT_WAVES) {
-         const int tile = 2 * tp + half;
-         int box = 0, n = 0, t0 = 0;
-#pragma unroll
-         for (int k = 0; k < LJT_GROUP_CELLS; ++k) {
-            const int st = __builtin_amdgcn_readlane(cT0, k);
-            if (tile >= st) { box = __builtin_amdgcn_readlane(cBox, k); n = __builtin_amdgcn_readlane(cN, k); t0 = st; }
-         }
-         const int slot = (tile - t0) * 32 + l31;
-         const bool have = tile < nTiles && slot < n;
-         double x = 1.0e30, y = 1.0e30, z = 1.0e30;           // padding: never inside a cutoff
-         if (have) { const size_t o = (size_t)box * a.cap + slot; x = a.rx[o]; y = a.ry[o]; z = a.rz[o]; }
-         if (tile < nTiles) { double* r = recs + (size_t)(tile * 32 + l31) * 3; r[0] = x; r[1] = y; r[2] = z; }
-         // box of the tile's real atoms, in fp32 rounded outwards (half-wave butterflies)
-         float lo[3] = { have ? (float)x : 3.0e38f, have ? (float)y : 3.0e38f, have ? (float)z : 3.0e38f };
-         float hi[3] = { have ? (float)x : -3.0e38f, have ? (float)y : -3.0e38f, have ? (float)z : -3.0e38f };
-#pragma unroll
-         for (int m = 16; m >= 1; m >>= 1)
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], m)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], m)); }
-         if (l31 == 0 && tile < nTiles) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-               tb[c * tbStride + tile] = lo[c] - (fabsf(lo[c]) * 1.2e-7f + 1.0e-30f);
-               tb[(3 + c) * tbStride + tile] = hi[c] + (fabsf(hi[c]) * 1.2e-7f + 1.0e-30f);
-            }
-         }
-      }
-      __syncthreads();
-
-      // ---- the cell's atoms, two per wave pass
-      for (int p = wave; 2 * p < ni; p += LJT_WAVES) {
-         const int iA = 2 * p, iB = (2 * p + 1 < ni) ? 2 * p + 1 : iA;          // odd count: the last atom works alone, B shadows it
-         const bool two = iB != iA;
-         const size_t iOff = (size_t)iBox * a.cap + (half ? iB : iA);
-         const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
-         // 1. prune: lane = tile
-         const float xAf = __shfl((float)xi, 0), yAf = __shfl((float)yi, 0), zAf = __shfl((float)zi, 0);
-         const float xBf = __shfl((float)xi, 32), yBf = __shfl((float)yi, 32), zBf = __shfl((float)zi, 32);
-         int nA = 0, nB = 0;
-         for (int tb0 = 0; tb0 < nTiles; tb0 += 64) {
-            const int tl = tb0 + lane;
-            const int tt = tl < nTiles ? tl : 0;
-            const float bx0 = tb[tt], by0 = tb[tbStride + tt], bz0 = tb[2 * tbStride + tt];
-            const float bx1 = tb[3 * tbStride + tt], by1 = tb[4 * tbStride + tt], bz1 = tb[5 * tbStride + tt];
-            const float ax = fmaxf(fmaxf(bx0 - xAf, xAf - bx1), 0.f), ay = fmaxf(fmaxf(by0 - yAf, yAf - by1), 0.f), az = fmaxf(fmaxf(bz0 - zAf, zAf - bz1), 0.f);
-            const float bx = fmaxf(fmaxf(bx0 - xBf, xBf - bx1), 0.f), by = fmaxf(fmaxf(by0 - yBf, yBf - by1), 0.f), bz = fmaxf(fmaxf(bz0 - zBf, zBf - bz1), 0.f);
-            const bool want = tl < nTiles && (ax * ax + ay * ay + az * az <= geo.rcPrune2 || bx * bx + by * by + bz * bz <= geo.rcPrune2);
-            unsigned long long visit = __ballot(want);
-            // 2. test the visited tiles: 32 candidates x {A, B}
-            while (visit) {
-               const int t = tb0 + (int)__builtin_ctzll(visit);
-               visit &= visit - 1;
-               const int rec = t * 32 + l31;
-               const double* __restrict__ r = recs + (size_t)rec * 3;
-               const double dx = xi - r[0], dy = yi - r[1], dz = zi - r[2];
-               const double r2 = dx * dx + dy * dy + dz * dz;
-               const bool hit = r2 <= a.rc2 && r2 > 0.0;
-               const unsigned long long m = __ballot(hit);
-               const unsigned mA = (unsigned)m, mB = (unsigned)(m >> 32);
-               const int cA = __popc(mA), cB = __popc(mB);
-               // queue slot: lanes 0-31 append to A's queue, lanes 32-63 to B's (mbcnt counts A's hits too for them)
-               const int k = (half ? LJT_QCAP + nB - cA : nA) + __builtin_amdgcn_mbcnt_hi(mB, __builtin_amdgcn_mbcnt_lo(mA, 0u));
-               const int kLimit = half ? 2 * LJT_QCAP : LJT_QCAP;
-               if (hit && k < kLimit) q[k] = (unsigned short)rec;
-               nA += cA; nB += cB;
-            }
-         }
-         if (nA > LJT_QCAP) { qOver = true; nA = LJT_QCAP; }
-         if (nB > LJT_QCAP) { qOver = true; nB = LJT_QCAP; }
-         // 3. evaluate the queues densely: 64 pairs of A and 64 pairs of B per trip
-         const double xA = __shfl(xi, 0), yA = __shfl(yi, 0), zA = __shfl(zi, 0);
-         const double xB = __shfl(xi, 32), yB = __shfl(yi, 32), zB = __shfl(zi, 32);
-         double fA[4] = { 0.0, 0.0, 0.0, 0.0 }, fB[4] = { 0.0, 0.0, 0.0, 0.0 };
-         const int nMax = nA > nB ? nA : nB;
-         for (int b = 0; b < nMax; b += 64) {
-            const bool hA = b + lane < nA, hB = b + lane < nB;
-            const int jA = hA ? q[b + lane] : 0, jB = hB ? q[LJT_QCAP + b + lane] : 0;
-            const double* __restrict__ ra = recs + (size_t)jA * 3;
-            const double* __restrict__ rb = recs + (size_t)jB * 3;
-            const double ax = xA - ra[0], ay = yA - ra[1], az = zA - ra[2];
-            const double bx = xB - rb[0], by = yB - rb[1], bz = zB - rb[2];
-            const double sA = hA ? ax * ax + ay * ay + az * az : a.rc2, sB = hB ? bx * bx + by * by + bz * bz : a.rc2;
-            const double iA2 = rcp64(sA), iB2 = rcp64(sB);
-            const double uA = a.s6 * iA2 * iA2 * iA2, uB = a.s6 * iB2 * iB2 * iB2;
-            if (ENERGY) { fA[3] += hA ? __builtin_fma(uA, uA - 1.0, -a.eShift) : 0.0; fB[3] += hB ? __builtin_fma(uB, uB - 1.0, -a.eShift) : 0.0; }
-            const double wA = hA ? uA * iA2 * __builtin_fma(uA, 2.0, -1.0) : 0.0, wB = hB ? uB * iB2 * __builtin_fma(uB, 2.0, -1.0) : 0.0;
-            fA[0] = __builtin_fma(wA, ax, fA[0]); fA[1] = __builtin_fma(wA, ay, fA[1]); fA[2] = __builtin_fma(wA, az, fA[2]);
-            fB[0] = __builtin_fma(wB, bx, fB[0]); fB[1] = __builtin_fma(wB, by, fB[1]); fB[2] = __builtin_fma(wB, bz, fB[2]);
-         }
-         // 4. lane partials -> totals of A in lane 31, of B in lane 63 -> the cell's accumulators (this wave owns the pair in every group)
-#pragma unroll
-         for (int v = 0; v < (ENERGY ? 4 : 3); ++v) {
-            const double tot = pairSum(fA[v], fB[v]);
-            if (lane == 31) acc[iA * 4 + v] += tot;
-            if (lane == 63 && two) acc[iB * 4 + v] += tot;
-         }
-      }
-   }
-   __syncthreads();
-   const double fs = 24.0 * a.eps;
-   for (int i = threadIdx.x; i < ni; i += LJT_THREADS) {
-      const size_t io = (size_t)iBox * a.cap + i;
-      a.fx[io] = acc[i * 4] * fs; a.fy[io] = acc[i * 4 + 1] * fs; a.fz[io] = acc[i * 4 + 2] * fs;
-      if (ENERGY) a.e[io] = acc[i * 4 + 3] * 2.0 * a.eps;
-   }
-   if (tooMany && lane == 0) atomicOr(&status[0], 2);
-   if (qOver && lane == 0) atomicOr(&status[3], 4);
-}
