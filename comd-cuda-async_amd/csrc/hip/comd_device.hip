@@ -186,6 +186,7 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
    sim->rank = cfg->rank; g_rank = cfg->rank;
    sim->maxAtoms = cfg->maxAtoms;
    sim->needEnergy = 1;
+   sim->latticeConstant = cfg->latticeConstant;
    sim->do_eam = cfg->do_eam;
    sim->mass = cfg->mass;
    if (cfg->maxAtoms < 1 || cfg->maxAtoms > 1024) { fprintf(stderr, "AllocateGpu: maxAtoms %d outside [1,1024]\n", cfg->maxAtoms); exit(-1); }
@@ -357,7 +358,8 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.list, sim->atoms.neighborList.nNeighbors, sim->atoms.neighborList.lastR.x,
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
-                    sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients };
+                    sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
+                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
@@ -545,13 +547,13 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
          if (!wide) {
             const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, 0);
             static size_t attrSet = 0;
-            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-            hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+            hipLaunchKernelGGL((EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
          } else {
             const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
             static size_t attrSet = 0;
-            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-            hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND_WIDE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+            hipLaunchKernelGGL((EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND_WIDE, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
          }
       } else if (method == THREAD_ATOM || method == WARP_ATOM) {
          hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, true>), dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);
@@ -578,6 +580,46 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
       if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
       else                         hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
+   } else if (method == CTA_CELL && !getenv("COMD_EAM_CTA_PAIRS")) {
+      // wave per cell, four lanes per atom, neighbour rows built on the fly in the LDS (nl_kernels.h EAM_Force_cta_cell); any capacity <= 64
+      if (sim->maxAtoms > 64) { fprintf(stderr, "eamForce: -m cta_cell stages whole cells of at most 64 slots (maxAtoms = %d); use -m thread_atom\n", sim->maxAtoms); exit(-1); }
+      const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
+      const bool tablesInLds = tableBytes <= 32 * 1024;
+      const bool sameGrid = a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+      // a stencil of 27 cells at the perfect-lattice density + 30 % (thermal crowding, cells fuller than the mean), whole staging rounds of 64
+      const double cellVol = 1.0 / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);
+      const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
+      int stencil = (int)(27.0 * cellVol * 4.0 / (lat * lat * lat) * 1.30) + 16;
+      stencil = ((stencil + 63) / 64) * 64;
+      if (stencil < 128) stencil = 128;
+      if (stencil > 27 * sim->maxAtoms) stencil = ((27 * sim->maxAtoms + 63) / 64) * 64;
+      if (stencil > 1024) stencil = 1024;                    // beyond that a cell takes the thread-per-atom form inside the same kernel
+      // rows per atom: the cutoff sphere at that density + 50 %, a multiple of 8
+      const double rc = sim->eam_pot.cutoff;
+      int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
+      if (rows < 32) rows = 32;
+      // 4 waves per workgroup, one per SIMD (5 or 6 land unevenly on the four SIMDs of a CU: measured 3.4-3.7 ms against 2.6 at 80^3)
+      int waves = 4;
+      { const char* e = getenv("COMD_EAM_CTA_WAVES"); if (e && atoi(e) >= 1 && atoi(e) <= 8) waves = atoi(e); }
+      if (!sim->eam_pot.pairRows || sim->eam_pot.pairRowLen != rows) {        // first cta_cell launch: rows pass 1 leaves for pass 3
+         if (sim->eam_pot.pairRows) { HIP_CHECK(hipFree(sim->eam_pot.pairRows)); HIP_CHECK(hipFree(sim->eam_pot.pairRowCount)); }
+         const size_t slotsLocal = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
+         sim->eam_pot.pairRows = dalloc<unsigned short>(slotsLocal * rows, false);
+         sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal);
+         sim->eam_pot.pairRowLen = rows;
+      }
+      const size_t lds = eamCtaCellLdsBytes(STEP, a.rho.n, a.phi.n, tablesInLds, sameGrid, stencil, rows, waves);
+      if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
+      const int grid = ceilDiv(num_cells, waves * 8);        // each wave walks ~8 consecutive cells
+      if (tablesInLds) {
+         static size_t attrSet = 0;
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, true>), dim3(grid), dim3(64 * waves), lds, st, a, stencil, rows, sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->status);
+      } else {
+         static size_t attrSet = 0;
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, false>), dim3(grid), dim3(64 * waves), lds, st, a, stencil, rows, sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->status);
+      }
    } else if (method == CTA_CELL) {
       eamCtaCheckCapacity(sim);
       // funcfl tables (500 samples) live in the LDS; setfl tables (10000 samples, 80 KB each) stay in L2 and the LDS
@@ -590,13 +632,13 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (tablesInLds) {
          const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, tableBytes);
          static size_t attrSet = 0;       // the attribute belongs to the device function, i.e. to the process: keyed by the largest size asked for
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND, true, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         hipLaunchKernelGGL((EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND, true, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
       } else {
          const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
          static size_t attrSet = 0;
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, EAM_CTA_MAXCAND_WIDE, false, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND_WIDE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         hipLaunchKernelGGL((EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND_WIDE, false, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
       }
    } else {
       hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, false>), dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);

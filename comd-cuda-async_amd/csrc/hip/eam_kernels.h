@@ -160,7 +160,7 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
 
 template <int STEP, int MAXCAND, bool LDS_TABLES, bool SPLINE>
 __global__ __launch_bounds__(EAM_CTA_THREADS)
-void EAM_Force_cta_cell(EamArgs a, int* __restrict__ status)
+void EAM_Force_cta_cell_pairs(EamArgs a, int* __restrict__ status)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int NV = (STEP == 1) ? 5 : 3;                   // values reduced per atom: f (3) [+ e, rhobar]

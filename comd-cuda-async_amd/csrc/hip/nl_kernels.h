@@ -706,3 +706,286 @@ static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, 
    tableDoubles = (tableDoubles + 1) & ~(size_t)1;
    return (tableDoubles + (size_t)EAM_NL_WAVES * ((size_t)rec * stencilAtoms + 32 + 256)) * sizeof(double);      // + offsets/cells + row stash
 }
+
+
+// ====================================================================================================================
+// EAM_Force_cta_cell (method cta_cell, no Verlet lists): the list kernel above with the list built on the fly.
+//
+// Round 1's cta_cell kernel (eam_kernels.h, kept as EAM_Force_cta_cell_pairs for the spline / wide-cutoff fallbacks) tested one atom
+// pair against 64 candidates per instruction and compacted the hits with ballot + mbcnt into an LDS queue: per pair a chain of
+// LDS read -> arithmetic -> ballot -> LDS write -> LDS gather -> table gather -> cross-lane reduction, ~4000 cycles long, with three
+// waves per SIMD to hide it -- VALU 44 % busy, 47 % of the wave time parked (profiles/r01_summary.md).  Here a wave owns a cell the
+// way EAM_Force_nl_lds does: the 27-cell stencil is staged in the wave's LDS slice, FOUR LANES serve one atom, 16 atoms per round.
+//   build : two atoms at a time, all 64 lanes test 64 staged records per trip (one read of a record serves both atoms); ballot + mbcnt
+//           append the hits in record order to the atom's row of a [16][rows] LDS table -- the atom's in-cutoff neighbours, exactly;
+//   force : lane q evaluates rows q, q+4, ... two per trip, branch-free; quad-permute DPP adds the four partials;
+//   pipe  : while cell c is built and evaluated out of the LDS, the records of c+1 are in flight into registers and the
+//           description of c+2 (two dependent reads) is on its way.
+// No cross-lane traffic beyond the quad, no queue shared by 64 lanes, and per lane long runs of independent work.
+template <int STEP, bool LDS_TABLES>
+__global__ __launch_bounds__(512)
+void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* __restrict__ rowsG, unsigned short* __restrict__ rowCountG,
+                        int* __restrict__ status)
+{
+   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+   constexpr int REC = 3;                                    // doubles per staged atom: x, y, z (24-byte stride: conflict-free wave-wide reads);
+   constexpr int RECD = (STEP == 3) ? 1 : 0;                 // pass 3 keeps F' of the staged atoms in an array of its own
+   const int nRhoPad = a.rho.n + 3;
+   const int wavesPerBlock = blockDim.x >> 6;
+   const bool sameGrid = (STEP == 1) && LDS_TABLES && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+   double* sRho = (double*)ldsRaw;
+   double* sPhi = sRho + nRhoPad;
+   int tableDoubles = 0;
+   if (LDS_TABLES) {
+      tableDoubles = (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;
+      if (sameGrid) {
+         for (int t = threadIdx.x; t < nRhoPad; t += blockDim.x) { sRho[2 * t] = a.phi.values[t]; sRho[2 * t + 1] = a.rho.values[t]; }
+      } else {
+         for (int t = threadIdx.x; t < nRhoPad; t += blockDim.x) sRho[t] = a.rho.values[t];
+         if (STEP == 1) for (int t = threadIdx.x; t < a.phi.n + 3; t += blockDim.x) sPhi[t] = a.phi.values[t];
+      }
+      __syncthreads();
+   }
+   const TableView rhoT = makeTable(a.rho, LDS_TABLES ? sRho : a.rho.values), phiT = makeTable(a.phi, LDS_TABLES ? sPhi : a.phi.values);
+
+   const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
+   const int hitDoubles = (16 * rows * 2 + 7) / 8 + 8;       // [16 atoms][rows] 16-bit record numbers + [16] row lengths
+   double* __restrict__ sp = (double*)ldsRaw + ((tableDoubles + 1) & ~1) + (size_t)wave * ((REC + RECD) * stencilAtoms + 32 + hitDoubles);
+   double* __restrict__ sd = sp + REC * stencilAtoms;        // [stencilAtoms] F' (pass 3)
+   int* sOff = (int*)(sp + (REC + RECD) * stencilAtoms);     // [32]: exclusive record offsets of the 27 cells, [27] = total
+   int* sBox = sOff + 32;                                    // [32]
+   unsigned short* sHit = (unsigned short*)(sBox + 32);
+   int* sCnt = (int*)(sHit + 16 * rows);                     // [16] neighbours of the round's atoms
+
+   // cells are dealt to waves in contiguous runs so that neighbouring cells (shared stencil lines) meet in one L2
+   const int nWaves = gridDim.x * wavesPerBlock;
+   const int gw = xcdRemap(blockIdx.x, gridDim.x) * wavesPerBlock + wave;
+   const int per = (a.nCells + nWaves - 1) / nWaves;
+   const int ciBegin = gw * per;
+   const int ciEnd = (gw + 1) * per < a.nCells ? (gw + 1) * per : a.nCells;
+   constexpr int SR = 6;                                     // staged records a lane keeps in flight (384 per wave; larger stencils: a second, blocking trip)
+
+   auto cellOf = [&](int ci) { return a.cells ? a.cells[ci] : ci; };
+   int boxB = 0, cntB = 0, boxA = 0, cntA = 0;               // descriptions of the cell after next / of the cell being loaded
+   if (ciBegin < ciEnd)     { const int c = cellOf(ciBegin);     boxA = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntA = lane < 27 ? a.nAtoms[boxA] : 0; }
+   if (ciBegin + 1 < ciEnd) { const int c = cellOf(ciBegin + 1); boxB = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntB = lane < 27 ? a.nAtoms[boxB] : 0; }
+
+   double vx[SR], vy[SR], vz[SR], vd[SR];
+   constexpr int RJ = 4;                                     // 16-byte row chunks a lane keeps in flight (pass 3): 16 rows of up to 128 entries
+   uint4 rowReg[RJ];
+   int rowCnt = 0;
+   const int cpr = rows >> 3;                                // 16-byte chunks per row
+   int totalL = 0, niL = 0, iBoxL = 0;
+   // pass 3: the rows pass 1 left for the atoms of round i0 of cell iBox, 16 bytes per lane and chunk
+   auto fetchRows = [&](int iBox, int ni, int i0) {
+#pragma unroll
+      for (int j = 0; j < RJ; ++j) {
+         const int c = lane + 64 * j;
+         const int atom = c / cpr, part = c - atom * cpr;
+         rowReg[j] = make_uint4(0u, 0u, 0u, 0u);
+         if (atom < 16 && i0 + atom < ni) rowReg[j] = *reinterpret_cast<const uint4*>(rowsG + ((size_t)iBox * a.cap + i0 + atom) * rows + part * 8);
+      }
+      rowCnt = (lane < 16 && i0 + lane < ni) ? rowCountG[(size_t)iBox * a.cap + i0 + lane] : 0;      // lane = atom of the round
+   };
+   auto issueLoads = [&]() {
+      {
+         int incl = cntA;
+#pragma unroll
+         for (int d = 1; d < 32; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+         if (lane < 28) { sOff[lane] = incl - cntA; sBox[lane] = boxA; }      // lane 27: cnt = 0 -> sOff[27] = total
+      }
+      __builtin_amdgcn_wave_barrier();
+      totalL = uniform(sOff[27]); niL = uniform(sOff[1]); iBoxL = uniform(boxA);
+#pragma unroll
+      for (int g = 0; g < SR; ++g) {
+         const int t = g * 64 + lane;
+         const int tt = t < totalL ? t : 0;
+         int lo = 0;                                                    // largest k in [0, 26] with sOff[k] <= tt
+#pragma unroll
+         for (int step = 16; step >= 1; step >>= 1) { const int m = lo + step; if (m <= 26 && sOff[m] <= tt) lo = m; }
+         const size_t o = (size_t)sBox[lo] * a.cap + (tt - sOff[lo]);
+         vx[g] = a.rx[o]; vy[g] = a.ry[o]; vz[g] = a.rz[o];
+         if (STEP == 3) vd[g] = a.dfEmbed[o];
+      }
+      if (STEP == 3) fetchRows(iBoxL, niL, 0);
+   };
+   if (ciBegin < ciEnd) issueLoads();
+
+   bool over = false;
+   for (int ci = ciBegin; ci < ciEnd; ++ci) {
+      // (a) the loads of cell ci have been issued: land them in the LDS
+      const int total = totalL, ni = niL, iBox = iBoxL;
+      const bool fits = total <= stencilAtoms;
+      if (STEP == 3 && fits) {                               // rows of the first 16 atoms (prefetched with the records)
+#pragma unroll
+         for (int j = 0; j < RJ; ++j) {
+            const int c = lane + 64 * j;
+            if (c < 16 * cpr) *reinterpret_cast<uint4*>(sHit + c * 8) = rowReg[j];      // chunk c = atom (c / cpr), part (c % cpr): rows are contiguous
+         }
+         if (lane < 16) sCnt[lane] = rowCnt;
+      }
+      if (fits) {
+#pragma unroll
+         for (int g = 0; g < SR; ++g) {
+            const int t = g * 64 + lane;
+            if (t < total) {
+               double* r = sp + REC * t;
+               r[0] = vx[g]; r[1] = vy[g]; r[2] = vz[g];
+               if (STEP == 3) sd[t] = vd[g];
+            }
+         }
+         for (int t = SR * 64 + lane; t < total; t += 64) {     // stencils beyond 384 atoms: blocking trip (sOff/sBox still describe cell ci)
+            int lo = 0;
+#pragma unroll
+            for (int step = 16; step >= 1; step >>= 1) { const int m = lo + step; if (m <= 26 && sOff[m] <= t) lo = m; }
+            const size_t o = (size_t)sBox[lo] * a.cap + (t - sOff[lo]);
+            double* r = sp + REC * t;
+            r[0] = a.rx[o]; r[1] = a.ry[o]; r[2] = a.rz[o];
+            if (STEP == 3) sd[t] = a.dfEmbed[o];
+         }
+      }
+      __builtin_amdgcn_wave_barrier();
+
+      // (b) start cell ci+1 (its description arrived during cell ci-1) and ask for the description of ci+2
+      if (ci + 1 < ciEnd) {
+         boxA = boxB; cntA = cntB;
+         if (ci + 2 < ciEnd) { const int c = cellOf(ci + 2); boxB = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntB = lane < 27 ? a.nAtoms[boxB] : 0; }
+         issueLoads();
+      }
+      if (!fits) {      // a stencil larger than the LDS slice (small boxes have larger cells): thread-per-atom form, same tables
+         eamCellDirect<STEP, false>(a, iBox, lane, rhoT, phiT, sameGrid);
+         __builtin_amdgcn_wave_barrier();
+         continue;
+      }
+
+      // (c) 16 atoms per round: build their neighbour rows in the LDS, then evaluate them
+      for (int i0 = 0; i0 < ni; i0 += 16) {
+         // LANES PER ATOM: as many as the round's atoms leave room for (FCC Cu at 80^3: cells of 9 atoms -> 7 lanes each, 6 -> 10, 13 or 14 -> 4),
+         // so a sparsely filled cell does not idle two lanes out of five; lane = L * atom + q, lane q takes rows q, q + L, ...
+         const int nRound = ni - i0 < 16 ? ni - i0 : 16;
+         int L = 64 / nRound; if (L > 16) L = 16;
+         const int ia = (lane * ((65536 + L - 1) / L)) >> 16;          // lane / L (exact for lane < 64)
+         const int q = lane - ia * L;
+         const int i = i0 + ia;
+         const bool have = ia < nRound;
+         const int ii = have ? i : 0;
+         const double xi = sp[REC * ii], yi = sp[REC * ii + 1], zi = sp[REC * ii + 2];      // own cell is staged first: record i
+         const double dfi = (STEP == 3) ? sd[ii] : 0.0;
+         // pass 3 adds to the forces of pass 1: ask for them now, a whole round of arithmetic before they are needed
+         const size_t io = (size_t)iBox * a.cap + ii;
+         double f0x = 0.0, f0y = 0.0, f0z = 0.0;
+         if (STEP == 3 && have && q == 0) { f0x = a.fx[io]; f0y = a.fy[io]; f0z = a.fz[io]; }
+         unsigned short* __restrict__ myRow = sHit + (have ? ia : 0) * rows;
+         if (STEP == 3) {
+            // pass 3: the rows pass 1 left behind (same staging order: cells and occupancies do not change inside a force evaluation)
+            if (i0 != 0) {                                           // cells of more than 16 atoms: later rounds fetch their rows here (rowReg holds the next cell's)
+               for (int c = lane; c < 16 * cpr; c += 64) {
+                  const int atom = c / cpr, part = c - atom * cpr;
+                  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+                  if (i0 + atom < ni) v = *reinterpret_cast<const uint4*>(rowsG + ((size_t)iBox * a.cap + i0 + atom) * rows + part * 8);
+                  *reinterpret_cast<uint4*>(sHit + c * 8) = v;
+               }
+               if (lane < 16) sCnt[lane] = i0 + lane < ni ? rowCountG[(size_t)iBox * a.cap + i0 + lane] : 0;
+               __builtin_amdgcn_wave_barrier();
+            }
+         } else {
+            // build: two atoms at a time, all 64 lanes on 64 staged records per trip (one read of each record serves both distance
+            // tests); ballot + mbcnt append the hits, in record order, to the two atoms' rows
+            for (int pa = 0; pa < nRound; pa += 2) {
+               const int iA = i0 + pa, iB = pa + 1 < nRound ? iA + 1 : iA;
+               const double xA = sp[REC * iA], yA = sp[REC * iA + 1], zA = sp[REC * iA + 2];
+               const double xB = sp[REC * iB], yB = sp[REC * iB + 1], zB = sp[REC * iB + 2];
+               unsigned short* __restrict__ rowA = sHit + pa * rows;
+               unsigned short* __restrict__ rowB = rowA + rows;
+               int nA = 0, nB = 0;
+               for (int t0 = 0; t0 < total; t0 += 64) {
+                  const int t = t0 + lane;
+                  const int tt = t < total ? t : 0;
+                  const double px = sp[REC * tt], py = sp[REC * tt + 1], pz = sp[REC * tt + 2];
+                  const double ax = xA - px, ay = yA - py, az = zA - pz;
+                  const double bx = xB - px, by = yB - py, bz = zB - pz;
+                  const double r2A = ax * ax + ay * ay + az * az, r2B = bx * bx + by * by + bz * bz;
+                  // records 0 .. ni-1 are the cell itself: only they can be the atom (r2 = 0); lanes past the list re-read record 0
+                  const bool live = t < total;
+                  const bool hitA = live && r2A <= a.rc2 && t != iA;
+                  const bool hitB = live && r2B <= a.rc2 && t != iB;
+                  const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA), mB = __builtin_amdgcn_ballot_w64(hitB);
+                  const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+                  const int kB = nB + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+                  if (hitA && kA < rows) rowA[kA] = (unsigned short)t;
+                  if (hitB && kB < rows) rowB[kB] = (unsigned short)t;
+                  nA += __popcll(mA); nB += __popcll(mB);
+               }
+               if (lane == 0) { sCnt[pa] = nA; sCnt[pa + 1] = nB; }      // (with an odd atom count the last B repeats A and lands in an unused row)
+            }
+            __builtin_amdgcn_wave_barrier();
+         }
+         int n = have ? sCnt[ia] : 0;                        // in-cutoff neighbours of atom i (the same in its L lanes)
+         if (n > rows) { over = true; n = rows; }
+         __builtin_amdgcn_wave_barrier();
+         if (STEP == 1) {                                    // leave the rows for pass 3: 16 bytes per lane and chunk, rows contiguous
+            for (int c = lane; c < 16 * cpr; c += 64) {
+               const int atom = c / cpr, part = c - atom * cpr;
+               if (i0 + atom < ni) *reinterpret_cast<uint4*>(rowsG + ((size_t)iBox * a.cap + i0 + atom) * rows + part * 8) = *reinterpret_cast<const uint4*>(sHit + c * 8);
+            }
+            if (lane < nRound) rowCountG[(size_t)iBox * a.cap + i0 + lane] = (unsigned short)(sCnt[lane] < rows ? sCnt[lane] : rows);
+         }
+
+         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0;
+         // two pairs per trip, branch-free (a missing second pair is evaluated at r = cutoff and weighted 0)
+         for (int k0 = q; k0 < n; k0 += 2 * L) {             // this lane's rows: q, q + L, q + 2L, ... < n
+            const bool h1 = k0 + L < n;
+            const int j0 = myRow[k0], j1 = h1 ? myRow[k0 + L] : ii;
+            const double* r0 = sp + REC * j0; const double* r1 = sp + REC * j1;
+            const double dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
+            const double dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
+            const double s0 = dx0*dx0 + dy0*dy0 + dz0*dz0;
+            const double s1 = h1 ? dx1*dx1 + dy1*dy1 + dz1*dz1 : a.rc2;
+            const double ir0 = rsqrt64(s0), ir1 = rsqrt64(s1);
+            const double d0 = s0 * ir0, d1 = s1 * ir1;
+            double rho0, drho0, dphi0, rho1, drho1, dphi1;
+            if (STEP == 1) {
+               double phi0, phi1;
+               if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
+               else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
+               e += phi0 + (h1 ? phi1 : 0.0);
+               rb += rho0 + (h1 ? rho1 : 0.0);
+            } else {
+               interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
+               dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
+            }
+            dphi0 = dphi0 * ir0; dphi1 = h1 ? dphi1 * ir1 : 0.0;
+            fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
+            fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
+         }
+         // the L lanes of an atom are consecutive: a shift-down tree adds them into the first (quad-permute DPP when L is 4)
+         if (L == 4) {
+            fx = quadSum(fx); fy = quadSum(fy); fz = quadSum(fz);
+            if (STEP == 1) { e = quadSum(e); rb = quadSum(rb); }
+         } else {
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+               const bool take = q + d < L;
+               const double tx = __shfl_down(fx, d), ty = __shfl_down(fy, d), tz = __shfl_down(fz, d);
+               fx += take ? tx : 0.0; fy += take ? ty : 0.0; fz += take ? tz : 0.0;
+               if (STEP == 1) { const double te = __shfl_down(e, d), tr = __shfl_down(rb, d); e += take ? te : 0.0; rb += take ? tr : 0.0; }
+            }
+         }
+         if (have && q == 0) {
+            if (STEP == 1) { a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = 0.5 * e; a.rhobar[io] = rb; }
+            else           { a.fx[io] = f0x + fx; a.fy[io] = f0y + fy; a.fz[io] = f0z + fz; }
+         }
+         __builtin_amdgcn_wave_barrier();
+      }
+   }
+   if (__builtin_amdgcn_ballot_w64(over) != 0ull && lane == 0) atomicOr(&status[3], 1);
+}
+
+static inline size_t eamCtaCellLdsBytes(int step, int nRho, int nPhi, bool ldsTables, bool sameGrid, int stencilAtoms, int rows, int wavesPerBlock)
+{
+   const int rec = step == 3 ? 4 : 3;
+   size_t tableDoubles = 0;
+   if (ldsTables) tableDoubles = step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
+   tableDoubles = (tableDoubles + 1) & ~(size_t)1;
+   return (tableDoubles + (size_t)wavesPerBlock * ((size_t)rec * stencilAtoms + 32 + (16 * (size_t)rows * 2 + 7) / 8 + 8)) * sizeof(double);
+}

@@ -60,6 +60,11 @@ typedef struct EamPotentialGpu {
    InterpolationSplineObjectGpu phiS, rhoS;   /* allocated when GpuConfig.phiSpline / rhoSpline are given; F(rhobar) stays quadratic (gpu_utility.c:443) */
    real_t* rhobar;                     /* device [nTotalBoxes*maxAtoms] */
    real_t* dfEmbed;                    /* device [nTotalBoxes*maxAtoms] */
+   /* cta_cell: pass 1 leaves each atom's in-cutoff neighbours (16-bit numbers in the staging order of its cell's stencil) here and pass 3
+    * reads them back instead of testing the stencil again; allocated by the first cta_cell launch */
+   unsigned short* pairRows;           /* device [nLocalBoxes*maxAtoms][pairRowLen] */
+   unsigned short* pairRowCount;       /* device [nLocalBoxes*maxAtoms] */
+   int     pairRowLen;
 } EamPotentialGpu;
 
 /* gpu_types.h:98-112 */
@@ -142,6 +147,7 @@ typedef struct SimGpu {
    int          msgBoundAtoms;         /* > 0: load{Force,Position}BufferFromGpu flag status[2] when the listed cells hold more atoms than this
                                         * (the size both ends of a halo message agreed on beforehand, see CommTransport.sendrecv2sized) */
    void*        timing;                /* comdForceTiming*: event pool of this simulation, NULL = off */
+   real_t       latticeConstant;       /* GpuConfig.latticeConstant (0: 3.615): density estimate behind the LDS sizing of the cell kernels */
    /* fields the reference's host code assigns (timestep.c:229-236); kept so that those statements compile, not read by the library */
    HashTableGpu d_hashTable;
    int          genPairlist;
