@@ -384,7 +384,7 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
       if (st[0] & 2) fprintf(stderr, "a cell stencil holds more atoms than the cta_cell kernel can stage; ");
       if (st[1])     fprintf(stderr, "an atom moved beyond the halo region and was lost; ");
       if (st[2])     fprintf(stderr, "a halo message overflowed its buffer, or grew by more than 12.5 %% + 64 atoms in one step (COMD_HALO_HANDSHAKE=1 exchanges exact sizes); ");
-      if (st[3] & 1) fprintf(stderr, "an atom has more neighbours inside the cutoff than the EAM cta_cell pair queue holds (use -m thread_atom); ");
+      if (st[3] & 1) fprintf(stderr, "an atom has more neighbours inside the cutoff than a row of the EAM cta_cell kernel holds (1.5 x the FCC count; use -m thread_atom); ");
       if (st[3] & 2) fprintf(stderr, "an atom has more than %d neighbours inside cutoff + skin (raise --maxNeighbors); ", sim->atoms.neighborList.maxNeighbors);
       fprintf(stderr, "\n");
       exit(-1);
@@ -518,15 +518,26 @@ static EamArgs makeEamArgs(SimGpu* sim, int num_cells, int* cells_list)
    return a;
 }
 
-// EAM_Force_cta_cell stages `64 / cap` stencil cells per round of 64 lanes and addresses a lane's slot as lane & (cap - 1): the cell
-// capacity must be a power of two of at most 64 (chooseMaxAtoms picks one; --maxAtoms may not)
-static void eamCtaCheckCapacity(const SimGpu* sim)
+// thread per atom: lanes per cell = the fullest cell the host has seen (+ 2), as a power of two; persistent workgroups when the tables
+// sit in the LDS (8 per CU's worth of 256 CUs), one workgroup per 256 / lanesPerCell cells otherwise
+template <int STEP>
+static void launchEamThreadAtom(SimGpu* sim, const EamArgs& a, int num_cells, hipStream_t st, bool spline)
 {
-   const int cap = sim->maxAtoms;
-   if (cap > 64 || (cap & (cap - 1)) != 0) {
-      fprintf(stderr, "eamForce: -m cta_cell needs a link-cell capacity that is a power of two <= 64 (maxAtoms = %d); use --maxAtoms 16/32/64 or -m thread_atom\n", cap);
-      exit(-1);
+   int want = sim->max_atoms_cell > 0 ? sim->max_atoms_cell + 2 : sim->maxAtoms;
+   if (want > sim->maxAtoms) want = sim->maxAtoms;
+   int lanes = 4;
+   while (lanes < want && lanes < 256) lanes *= 2;
+   const int nGroups = ceilDiv(num_cells, 256 / lanes);
+   const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
+   if (spline) {
+      hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, true, false>), dim3(nGroups), dim3(256), 0, st, a, lanes);
+   } else if (tableBytes <= 32 * 1024) {
+      const int grid = nGroups < 4096 ? nGroups : 4096;
+      hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, false, true>), dim3(grid), dim3(256), tableBytes, st, a, lanes);
+   } else {
+      hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, false, false>), dim3(nGroups), dim3(256), 0, st, a, lanes);
    }
+   LAUNCH_CHECK();
 }
 
 template <int STEP>
@@ -538,30 +549,13 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
    if (spline) {
       // -P (gpu_kernels.cu:164-226): cubic splines in r^2 for phi and rho, coefficient tables read through L2 (16 KB each for funcfl)
       if (!a.phiS.coefficients || !a.rhoS.coefficients) { fprintf(stderr, "eamForce: spline != 0 but no spline tables were given to AllocateGpu\n"); exit(-1); }
-      if (method == CTA_CELL) {
-         eamCtaCheckCapacity(sim);
-         const int wide = sim->eam_pot.cutoff > 5.2;          // same stencil-list capacities as the quadratic path (funcfl / setfl cutoffs)
-         int grid = ceilDiv(num_cells, EAM_CTA_WAVES);
-         if (grid > 2048) grid = 2048;
-         if (grid < 8) grid = 8;
-         if (!wide) {
-            const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, 0);
-            static size_t attrSet = 0;
-            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-            hipLaunchKernelGGL((EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
-         } else {
-            const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
-            static size_t attrSet = 0;
-            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND_WIDE, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-            hipLaunchKernelGGL((EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND_WIDE, false, true>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
-         }
-      } else if (method == THREAD_ATOM || method == WARP_ATOM) {
-         hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, true>), dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);
-      } else {
+      if (method != CTA_CELL && method != THREAD_ATOM && method != WARP_ATOM) {
          fprintf(stderr, "eamForce: the spline tables (-P) are implemented for the cell methods (thread_atom, cta_cell)\n"); exit(-1);
       }
-      LAUNCH_CHECK();
-      return;
+      if (method != CTA_CELL) {
+         launchEamThreadAtom<STEP>(sim, a, num_cells, st, true);
+         return;
+      }
    }
    if ((method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat == 2) {
       NeighborListGpu* n = &sim->atoms.neighborList;
@@ -580,11 +574,10 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
       if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
       else                         hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
-   } else if (method == CTA_CELL && !getenv("COMD_EAM_CTA_PAIRS")) {
-      // wave per cell, four lanes per atom, neighbour rows built on the fly in the LDS (nl_kernels.h EAM_Force_cta_cell); any capacity <= 64
-      if (sim->maxAtoms > 64) { fprintf(stderr, "eamForce: -m cta_cell stages whole cells of at most 64 slots (maxAtoms = %d); use -m thread_atom\n", sim->maxAtoms); exit(-1); }
+   } else if (method == CTA_CELL) {
+      // wave per cell, neighbour rows built on the fly in the LDS (nl_kernels.h EAM_Force_cta_cell); any cell capacity
       const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
-      const bool tablesInLds = tableBytes <= 32 * 1024;
+      const bool tablesInLds = !spline && tableBytes <= 32 * 1024;      // funcfl tables (500 samples) live in the LDS; setfl (10000) and spline coefficients stay in L2
       const bool sameGrid = a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
       // a stencil of 27 cells at the perfect-lattice density + 30 % (thermal crowding, cells fuller than the mean), whole staging rounds of 64
       const double cellVol = 1.0 / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);
@@ -611,37 +604,17 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       const size_t lds = eamCtaCellLdsBytes(STEP, a.rho.n, a.phi.n, tablesInLds, sameGrid, stencil, rows, waves);
       if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
       const int grid = ceilDiv(num_cells, waves * 8);        // each wave walks ~8 consecutive cells
-      if (tablesInLds) {
-         static size_t attrSet = 0;
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, true>), dim3(grid), dim3(64 * waves), lds, st, a, stencil, rows, sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->status);
-      } else {
-         static size_t attrSet = 0;
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, false>), dim3(grid), dim3(64 * waves), lds, st, a, stencil, rows, sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->status);
-      }
-   } else if (method == CTA_CELL) {
-      eamCtaCheckCapacity(sim);
-      // funcfl tables (500 samples) live in the LDS; setfl tables (10000 samples, 80 KB each) stay in L2 and the LDS
-      // goes to a wider candidate list instead (longer cutoff -> more atoms per stencil)
-      const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
-      const int tablesInLds = tableBytes <= 32 * 1024;
-      int grid = ceilDiv(num_cells, EAM_CTA_WAVES);
-      if (grid > 2048) grid = 2048;             // persistent: 8 workgroups per CU's worth, each wave strides over cells
-      if (grid < 8) grid = 8;                   // the kernel deals cell ranges to XCDs (blockIdx % 8): every XCD needs a workgroup
-      if (tablesInLds) {
-         const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND, tableBytes);
-         static size_t attrSet = 0;       // the attribute belongs to the device function, i.e. to the process: keyed by the largest size asked for
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-         hipLaunchKernelGGL((EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND, true, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
-      } else {
-         const size_t lds = eamCtaLdsBytes(STEP, EAM_CTA_MAXCAND_WIDE, 0);
-         static size_t attrSet = 0;
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND_WIDE, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
-         hipLaunchKernelGGL((EAM_Force_cta_cell_pairs<STEP, EAM_CTA_MAXCAND_WIDE, false, false>), dim3(grid), dim3(EAM_CTA_THREADS), lds, st, a, sim->status);
-      }
+#define COMD_LAUNCH_EAM_CTA(TAB, SPL) do { \
+         static size_t attrSet = 0; \
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, TAB, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; } \
+         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, TAB, SPL>), dim3(grid), dim3(64 * waves), lds, st, a, stencil, rows, sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->status); } while (0)
+      if (spline)           COMD_LAUNCH_EAM_CTA(false, true);
+      else if (tablesInLds) COMD_LAUNCH_EAM_CTA(true, false);
+      else                  COMD_LAUNCH_EAM_CTA(false, false);
+#undef COMD_LAUNCH_EAM_CTA
    } else {
-      hipLaunchKernelGGL((EAM_Force_thread_atom<STEP, false>), dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, st, a);
+      launchEamThreadAtom<STEP>(sim, a, num_cells, st, false);
+      return;
    }
    LAUNCH_CHECK();
 }

@@ -711,7 +711,7 @@ static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, 
 // ====================================================================================================================
 // EAM_Force_cta_cell (method cta_cell, no Verlet lists): the list kernel above with the list built on the fly.
 //
-// Round 1's cta_cell kernel (eam_kernels.h, kept as EAM_Force_cta_cell_pairs for the spline / wide-cutoff fallbacks) tested one atom
+// Round 1's cta_cell kernel tested one atom
 // pair against 64 candidates per instruction and compacted the hits with ballot + mbcnt into an LDS queue: per pair a chain of
 // LDS read -> arithmetic -> ballot -> LDS write -> LDS gather -> table gather -> cross-lane reduction, ~4000 cycles long, with three
 // waves per SIMD to hide it -- VALU 44 % busy, 47 % of the wave time parked (profiles/r01_summary.md).  Here a wave owns a cell the
@@ -722,7 +722,7 @@ static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, 
 //   pipe  : while cell c is built and evaluated out of the LDS, the records of c+1 are in flight into registers and the
 //           description of c+2 (two dependent reads) is on its way.
 // No cross-lane traffic beyond the quad, no queue shared by 64 lanes, and per lane long runs of independent work.
-template <int STEP, bool LDS_TABLES>
+template <int STEP, bool LDS_TABLES, bool SPLINE>
 __global__ __launch_bounds__(512)
 void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* __restrict__ rowsG, unsigned short* __restrict__ rowCountG,
                         int* __restrict__ status)
@@ -853,7 +853,7 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
          issueLoads();
       }
       if (!fits) {      // a stencil larger than the LDS slice (small boxes have larger cells): thread-per-atom form, same tables
-         eamCellDirect<STEP, false>(a, iBox, lane, rhoT, phiT, sameGrid);
+         eamCellDirect<STEP, SPLINE>(a, iBox, lane, rhoT, phiT, sameGrid);
          __builtin_amdgcn_wave_barrier();
          continue;
       }
@@ -941,20 +941,33 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
             const double dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
             const double s0 = dx0*dx0 + dy0*dy0 + dz0*dz0;
             const double s1 = h1 ? dx1*dx1 + dy1*dy1 + dz1*dz1 : a.rc2;
-            const double ir0 = rsqrt64(s0), ir1 = rsqrt64(s1);
-            const double d0 = s0 * ir0, d1 = s1 * ir1;
             double rho0, drho0, dphi0, rho1, drho1, dphi1;
-            if (STEP == 1) {
-               double phi0, phi1;
-               if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
-               else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
-               e += phi0 + (h1 ? phi1 : 0.0);
-               rb += rho0 + (h1 ? rho1 : 0.0);
+            if (SPLINE) {                                    // -P: cubic splines in r^2 give (1/r) d/dr directly, no square root
+               interpolateSpline(a.rhoS, s0, rho0, drho0); interpolateSpline(a.rhoS, s1, rho1, drho1);
+               if (STEP == 1) {
+                  double phi0, phi1;
+                  interpolateSpline(a.phiS, s0, phi0, dphi0); interpolateSpline(a.phiS, s1, phi1, dphi1);
+                  e += phi0 + (h1 ? phi1 : 0.0);
+                  rb += rho0 + (h1 ? rho1 : 0.0);
+               } else {
+                  dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
+               }
+               dphi1 = h1 ? dphi1 : 0.0;
             } else {
-               interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
-               dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
+               const double ir0 = rsqrt64(s0), ir1 = rsqrt64(s1);
+               const double d0 = s0 * ir0, d1 = s1 * ir1;
+               if (STEP == 1) {
+                  double phi0, phi1;
+                  if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
+                  else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
+                  e += phi0 + (h1 ? phi1 : 0.0);
+                  rb += rho0 + (h1 ? rho1 : 0.0);
+               } else {
+                  interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
+                  dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
+               }
+               dphi0 = dphi0 * ir0; dphi1 = h1 ? dphi1 * ir1 : 0.0;
             }
-            dphi0 = dphi0 * ir0; dphi1 = h1 ? dphi1 * ir1 : 0.0;
             fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
             fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
          }

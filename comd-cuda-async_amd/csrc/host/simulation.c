@@ -53,12 +53,10 @@ static int chooseMaxAtoms(int latticeMax, real_t delta, const LinkCell* boxes, i
    real_t minBox = fmin(boxes->boxSize[0], fmin(boxes->boxSize[1], boxes->boxSize[2]));
    int want = (int)ceil(latticeMax * (1.10 + 3.0 * delta / minBox)) + 8;
    if (!doeam) return ((want + 63) / 64) * 64;
-   /* the EAM list kernels take any capacity up to 64; the cell kernels (cta_cell staging) want a power of two.  Cells of
-    * cutoff + skin hold 4..32 atoms of a perfect lattice: 44 slots instead of 64 is a third less for every slot-wise kernel */
-   if (useNL && want <= 64) return ((want + 3) / 4) * 4;
-   int cap = 16;
-   while (cap < want) cap *= 2;
-   return cap;
+   /* the EAM kernels take any capacity: a multiple of 4 (16-byte rows of ints).  Cells of cutoff (+ skin) hold 4..32 atoms of a
+    * perfect lattice: 20 or 44 slots instead of 32 or 64 is a third less for every slot-wise kernel and for the atom arrays */
+   (void)useNL;
+   return ((want + 3) / 4) * 4;
 }
 
 static int cmpInt(const void* a, const void* b) { return (*(const int*)a > *(const int*)b) - (*(const int*)a < *(const int*)b); }
@@ -153,15 +151,6 @@ SimFlat* initSimulationHost(Command cmd)
       int localMax = countFccLattice(cmd.nx, cmd.ny, cmd.nz, latticeConstant, sim->domain, sim->boxes), globalMaxOcc;
       maxIntParallel(&localMax, &globalMaxOcc, 1);
       cap = chooseMaxAtoms(globalMaxOcc, cmd.initialDelta, sim->boxes, cmd.doeam, sim->useNL);
-   }
-   /* EAM_Force_cta_cell stages 64 / cap stencil cells per round and masks slots with cap - 1 (eam_kernels.h): a capacity that is not a
-    * power of two, or exceeds a wave, would hang the staging loop or drop slots without a word.  Refuse it here, before any device work. */
-   if (cmd.doeam && sim->method == CTA_CELL && (cap > 64 || (cap & (cap - 1)) != 0)) {
-      if (printRank())
-         fprintf(stderr, "Error: -e -m cta_cell needs a link-cell capacity that is a power of two <= 64; %s %d.\n"
-                 "       Use --maxAtoms 16, 32 or 64, or -m thread_atom (any capacity).\n",
-                 cmd.maxAtoms > 0 ? "--maxAtoms is" : "this box needs", cap);
-      exit(-1);
    }
    sim->boxes->maxAtoms = cap;
    sim->atoms = initAtoms(sim->boxes);

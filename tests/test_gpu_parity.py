@@ -46,6 +46,25 @@ def test_forces_match_oracle(gpu, orc, method, eam, n, delta):
             assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < 1e-12
 
 
+@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("cap", [44, 100, 128])
+def test_eam_any_cell_capacity(gpu, orc, method, cap):
+    """--maxAtoms that is neither a power of two nor below a wave (round 1's cta_cell kernel addressed slots as lane & (cap - 1) and
+    hung or dropped slots for such values): forces, energies, rhobar and F' against the oracle, then a short trace."""
+    with gpu.Simulation(_args(8, 1, 0.1, method, ["--maxAtoms", cap])) as sim:
+        assert sim.max_atoms == cap
+        o = orc.Oracle(8, eam=1, delta=0.1, cap=max(cap, 64))
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * np.abs(fo).max()
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < 1e-12
+        assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < 1e-12
+        sim.step(10)
+        o.step(10)
+        (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
+        assert abs((ep + ek) - (op + ok)) / ng < TOL["energy_per_atom_trace"]
+
+
 @pytest.mark.parametrize("eam,n,method", [(1, 10, "cta_cell"), (1, 10, "thread_atom"), (0, 14, "cta_cell"), (0, 14, "thread_atom")])
 def test_overlap_mode_small_interior(gpu, orc, eam, n, method):
     """-a 1 on one rank: interior cells (27 for EAM 10^3, 8 for LJ 14^3) on one stream, the two boundary rings on the other.
