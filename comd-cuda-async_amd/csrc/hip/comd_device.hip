@@ -671,6 +671,16 @@ extern "C" void advanceVelocityPositionGpu(SimGpu* sim, real_t dtKick, real_t dt
    LAUNCH_CHECK();
 }
 
+extern "C" void advanceVelocityVelocityPositionGpu(SimGpu* sim, real_t dtKick1, real_t dtKick2, real_t dtDrift)
+{
+   const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
+   hipLaunchKernelGGL(AdvanceVelocityVelocityPosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
+                      sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.iSpecies, sim->species_mass,
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick1, dtKick2, dtDrift);
+   LAUNCH_CHECK();
+}
+
 extern "C" void computeEnergy(SimGpu* sim, real_t* eLocal)
 {
    hipStream_t st = S(sim->boundary_stream);
@@ -743,14 +753,36 @@ extern "C" void getAtomMsgSoAPtr(char* buffer, AtomMsgSoA* m, int n)
    m->ry = m->rx + n; m->rz = m->ry + n; m->px = m->rz + n; m->py = m->px + n; m->pz = m->py + n;
 }
 
+static int maxInt(int a, int b) { return a > b ? a : b; }
+
+// both faces of an axis phase: one scan launch (two jobs), one pack launch (blockIdx.y = face)
+extern "C" void compactCellsGpu2(char* workM, char* workP, const int nCells[2], int* const d_cellList[2], SimGpu* sim, int* const d_cellOffsets[2],
+                                 const real_t shiftM[3], const real_t shiftP[3], const int capacityAtoms[2], comdStream_t stream)
+{
+   hipStream_t st = S(stream);
+   const int nFaces = workP ? 2 : 1;
+   ScanJobs jobs;
+   AtomPackJob pj[2];
+   char* work[2] = { workM, workP };
+   const real_t* shift[2] = { shiftM, shiftP };
+   for (int f = 0; f < 2; ++f) {
+      const int k = f < nFaces ? f : 0;
+      jobs.list[f] = d_cellList[k]; jobs.n[f] = nCells[k]; jobs.out[f] = d_cellOffsets[k]; jobs.total[f] = (int*)work[k];
+      pj[f].msg = work[k]; pj[f].list = d_cellList[k]; pj[f].offsets = d_cellOffsets[k]; pj[f].nCells = nCells[k];
+      pj[f].sx = shift[k][0]; pj[f].sy = shift[k][1]; pj[f].sz = shift[k][2]; pj[f].capacityAtoms = capacityAtoms[k];
+   }
+   hipLaunchKernelGGL(ScanCellCountsBatch, dim3(nFaces), dim3(1024), 0, st, sim->boxes.nAtoms, jobs);
+   hipLaunchKernelGGL(LoadAtomsBufferPacked, dim3(nFaces == 2 ? maxInt(nCells[0], nCells[1]) : nCells[0], nFaces), dim3(sortBlock(sim->maxAtoms)), 0, st,
+                      pj[0], pj[1], atomArrays(sim), sim->boxes.nAtoms, sim->maxAtoms, sim->status);
+   LAUNCH_CHECK();
+}
+
 extern "C" void compactCellsGpu(char* work_d, int nCells, int* d_cellList, SimGpu* sim, int* d_cellOffsets,
                                 const real_t shift[3], int capacityAtoms, comdStream_t stream)
 {
-   hipStream_t st = S(stream);
-   hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)work_d);
-   hipLaunchKernelGGL(LoadAtomsBufferPacked, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, work_d, d_cellList, d_cellOffsets, nCells,
-                      atomArrays(sim), sim->boxes.nAtoms, sim->maxAtoms, shift[0], shift[1], shift[2], capacityAtoms, sim->status);
-   LAUNCH_CHECK();
+   const int n[2] = { nCells, 0 }; int* const lists[2] = { d_cellList, nullptr }; int* const offs[2] = { d_cellOffsets, nullptr };
+   const int caps[2] = { capacityAtoms, 0 };
+   compactCellsGpu2(work_d, nullptr, n, lists, sim, offs, shift, shift, caps, stream);
 }
 
 extern "C" void comdReadDeviceInt2(const int* d_a, const int* d_b, int out[2], comdStream_t stream)
@@ -772,41 +804,94 @@ extern "C" int atomMsgCountGpu(SimGpu* sim, const char* msg_d, comdStream_t stre
    return comdReadDeviceInt((const int*)msg_d, stream);
 }
 
-extern "C" void unloadAtomsBufferToGpu(const char* msg_d, int nBuf, int maxAtomsInMsg, SimGpu* sim, comdStream_t stream)
+// msgB == NULL: one message
+extern "C" void unloadAtomsBufferToGpu2(const char* msgA, int nBufA, int maxAtomsA, const char* msgB, int nBufB, int maxAtomsB, SimGpu* sim, comdStream_t stream)
 {
-   const int bound = nBuf >= 0 ? nBuf : maxAtomsInMsg;
+   const int boundA = nBufA >= 0 ? nBufA : maxAtomsA, boundB = msgB ? (nBufB >= 0 ? nBufB : maxAtomsB) : 0;
+   const int bound = maxInt(boundA, boundB);
    if (bound <= 0) return;
-   hipLaunchKernelGGL(UnloadAtomsBufferPacked, dim3(ceilDiv(bound, 256)), dim3(256), 0, S(stream), msg_d, nBuf, maxAtomsInMsg,
+   AtomUnpackJob a = { msgA, nBufA, maxAtomsA }, b = { msgB ? msgB : msgA, msgB ? nBufB : 0, msgB ? maxAtomsB : 0 };
+   hipLaunchKernelGGL(UnloadAtomsBufferPacked, dim3(ceilDiv(bound, 256), msgB ? 2 : 1), dim3(256), 0, S(stream), a, b,
                       atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, sim->boxes, sim->maxAtoms);
    LAUNCH_CHECK();
+}
+
+extern "C" void unloadAtomsBufferToGpu(const char* msg_d, int nBuf, int maxAtomsInMsg, SimGpu* sim, comdStream_t stream)
+{
+   unloadAtomsBufferToGpu2(msg_d, nBuf, maxAtomsInMsg, nullptr, 0, 0, sim, stream);
 }
 
 extern "C" void scanCellListsGpu(SimGpu* sim, int nLists, int** d_cellLists, const int* nCells, int** d_cellOffsets, comdStream_t stream)
 {
    if (nLists < 1 || nLists > 12) { fprintf(stderr, "scanCellListsGpu: 1..12 lists per call\n"); exit(-1); }
    ScanJobs jobs;
-   for (int i = 0; i < nLists; ++i) { jobs.list[i] = d_cellLists[i]; jobs.n[i] = nCells[i]; jobs.out[i] = d_cellOffsets[i]; }
+   for (int i = 0; i < 12; ++i) { const int k = i < nLists ? i : 0; jobs.list[i] = d_cellLists[k]; jobs.n[i] = nCells[k]; jobs.out[i] = d_cellOffsets[k]; jobs.total[i] = nullptr; }
    hipLaunchKernelGGL(ScanCellCountsBatch, dim3(nLists), dim3(1024), 0, S(stream), sim->boxes.nAtoms, jobs);
+   LAUNCH_CHECK();
+}
+
+static SlotJob slotJob(const real_t* buf, int nCells, int* list, int* offsets, int bound, const real_t* shift)
+{
+   SlotJob j; j.buf = (double*)buf; j.list = list; j.offsets = offsets; j.nCells = nCells; j.boundAtoms = bound;
+   j.sx = shift ? shift[0] : 0.0; j.sy = shift ? shift[1] : 0.0; j.sz = shift ? shift[2] : 0.0;
+   return j;
+}
+
+// scan the listed cells' occupancies unless comdForceScansReady(1) says the batched scan of the step already did
+static void scanIfNeeded(SimGpu* sim, int nFaces, const int* nCells, int* const* lists, int* const* offsets, hipStream_t st)
+{
+   if (sim->forceScansReady) return;
+   ScanJobs jobs;
+   for (int i = 0; i < 12; ++i) { const int k = i < nFaces ? i : 0; jobs.list[i] = lists[k]; jobs.n[i] = nCells[k]; jobs.out[i] = offsets[k]; jobs.total[i] = nullptr; }
+   hipLaunchKernelGGL(ScanCellCountsBatch, dim3(nFaces), dim3(1024), 0, st, sim->boxes.nAtoms, jobs);
+}
+
+// kind 0: dF/drho (1 real per atom), 1: positions + shift (3 reals per atom); bufP == NULL: one face
+static void loadSlotBuffers(int kind, real_t* bufM, real_t* bufP, const int nCells[2], int* const lists[2], int* const offsets[2], const int bounds[2],
+                            const real_t* shiftM, const real_t* shiftP, SimGpu* sim, hipStream_t st)
+{
+   const int nFaces = bufP ? 2 : 1;
+   scanIfNeeded(sim, nFaces, nCells, lists, offsets, st);
+   const SlotJob a = slotJob(bufM, nCells[0], lists[0], offsets[0], bounds[0], shiftM);
+   const SlotJob b = bufP ? slotJob(bufP, nCells[1], lists[1], offsets[1], bounds[1], shiftP) : a;
+   const dim3 grid(nFaces == 2 ? maxInt(nCells[0], nCells[1]) : nCells[0], nFaces), block(sortBlock(sim->maxAtoms));
+   if (kind == 0) hipLaunchKernelGGL(LoadForceBuffer, grid, block, 0, st, a, b, sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms, sim->status);
+   else           hipLaunchKernelGGL(LoadPositionBuffer, grid, block, 0, st, a, b, sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->maxAtoms, sim->status);
+   LAUNCH_CHECK();
+}
+
+static void unloadSlotBuffers(int kind, const real_t* bufA, const real_t* bufB, const int nCells[2], int* const lists[2], int* const offsets[2],
+                              SimGpu* sim, hipStream_t st)
+{
+   const int nFaces = bufB ? 2 : 1;
+   scanIfNeeded(sim, nFaces, nCells, lists, offsets, st);
+   const SlotJob a = slotJob(bufA, nCells[0], lists[0], offsets[0], 0, nullptr);
+   const SlotJob b = bufB ? slotJob(bufB, nCells[1], lists[1], offsets[1], 0, nullptr) : a;
+   const dim3 grid(nFaces == 2 ? maxInt(nCells[0], nCells[1]) : nCells[0], nFaces), block(sortBlock(sim->maxAtoms));
+   if (kind == 0) hipLaunchKernelGGL(UnloadForceBuffer, grid, block, 0, st, a, b, sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
+   else           hipLaunchKernelGGL(UnloadPositionBuffer, grid, block, 0, st, a, b, sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->maxAtoms);
    LAUNCH_CHECK();
 }
 
 extern "C" void loadForceBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
 {
-   hipStream_t st = S(stream);
-   if (!sim->forceScansReady) hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
-   hipLaunchKernelGGL(LoadForceBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, gpu_buf, d_cellList, d_cellOffsets,
-                      sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms, nCells, sim->msgBoundAtoms, sim->status);
-   LAUNCH_CHECK();
+   const int n[2] = { nCells, 0 }; int* const l[2] = { d_cellList, nullptr }; int* const o[2] = { d_cellOffsets, nullptr }; const int b[2] = { sim->msgBoundAtoms, 0 };
+   loadSlotBuffers(0, gpu_buf, nullptr, n, l, o, b, nullptr, nullptr, sim, S(stream));
 }
 
 extern "C" void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
 {
-   hipStream_t st = S(stream);
-   if (!sim->forceScansReady) hipLaunchKernelGGL(ScanCellCounts, dim3(1), dim3(1024), 0, st, sim->boxes.nAtoms, d_cellList, nCells, d_cellOffsets, (int*)nullptr);
-   hipLaunchKernelGGL(UnloadForceBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, st, gpu_buf, d_cellList, d_cellOffsets,
-                      sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
-   LAUNCH_CHECK();
+   const int n[2] = { nCells, 0 }; int* const l[2] = { d_cellList, nullptr }; int* const o[2] = { d_cellOffsets, nullptr };
+   unloadSlotBuffers(0, gpu_buf, nullptr, n, l, o, sim, S(stream));
 }
+
+extern "C" void loadForceBufferFromGpu2(real_t* bufM, real_t* bufP, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
+                                        const int boundAtoms[2], SimGpu* sim, comdStream_t stream)
+{ loadSlotBuffers(0, bufM, bufP, nCells, d_cellList, d_cellOffsets, boundAtoms, nullptr, nullptr, sim, S(stream)); }
+
+extern "C" void unloadForceBufferToGpu2(const real_t* bufA, const real_t* bufB, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
+                                        SimGpu* sim, comdStream_t stream)
+{ unloadSlotBuffers(0, bufA, bufB, nCells, d_cellList, d_cellOffsets, sim, S(stream)); }
 
 // ---- Verlet neighbour lists ------------------------------------------------------------------------------------------------
 extern "C" void emptyNeighborListGpu(SimGpu* sim, int)
@@ -935,15 +1020,32 @@ COMD_ABSENT(unloadForceScanCells) COMD_ABSENT(exchangeDataForceGpu_KI) COMD_ABSE
 
 extern "C" void loadPositionBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, const real_t shift[3], SimGpu* sim, comdStream_t stream)
 {
-   hipLaunchKernelGGL(LoadPositionBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, S(stream), gpu_buf, d_cellList, d_cellOffsets,
-                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->maxAtoms, shift[0], shift[1], shift[2],
-                      nCells, sim->msgBoundAtoms, sim->status);
-   LAUNCH_CHECK();
+   const int n[2] = { nCells, 0 }; int* const l[2] = { d_cellList, nullptr }; int* const o[2] = { d_cellOffsets, nullptr }; const int b[2] = { sim->msgBoundAtoms, 0 };
+   const int ready = sim->forceScansReady; sim->forceScansReady = 1;        // the offsets of a position exchange are those of the last list build
+   loadSlotBuffers(1, gpu_buf, nullptr, n, l, o, b, shift, nullptr, sim, S(stream));
+   sim->forceScansReady = ready;
 }
 
 extern "C" void unloadPositionBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream)
 {
-   hipLaunchKernelGGL(UnloadPositionBuffer, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), 0, S(stream), gpu_buf, d_cellList, d_cellOffsets,
-                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->maxAtoms);
-   LAUNCH_CHECK();
+   const int n[2] = { nCells, 0 }; int* const l[2] = { d_cellList, nullptr }; int* const o[2] = { d_cellOffsets, nullptr };
+   const int ready = sim->forceScansReady; sim->forceScansReady = 1;
+   unloadSlotBuffers(1, gpu_buf, nullptr, n, l, o, sim, S(stream));
+   sim->forceScansReady = ready;
+}
+
+extern "C" void loadPositionBufferFromGpu2(real_t* bufM, real_t* bufP, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
+                                           const int boundAtoms[2], const real_t shiftM[3], const real_t shiftP[3], SimGpu* sim, comdStream_t stream)
+{
+   const int ready = sim->forceScansReady; sim->forceScansReady = 1;
+   loadSlotBuffers(1, bufM, bufP, nCells, d_cellList, d_cellOffsets, boundAtoms, shiftM, shiftP, sim, S(stream));
+   sim->forceScansReady = ready;
+}
+
+extern "C" void unloadPositionBufferToGpu2(const real_t* bufA, const real_t* bufB, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
+                                           SimGpu* sim, comdStream_t stream)
+{
+   const int ready = sim->forceScansReady; sim->forceScansReady = 1;
+   unloadSlotBuffers(1, bufA, bufB, nCells, d_cellList, d_cellOffsets, sim, S(stream));
+   sim->forceScansReady = ready;
 }

@@ -177,35 +177,6 @@ void EAM_Force_thread_atom_nl(EamArgs a, NlView nl)
    if (STEP == 1) { a.e[iSlot] = 0.5 * e; a.rhobar[iSlot] = rb; }
 }
 
-// ---- positional refresh of the halo copies between list builds (slot order == the sender's slot order) ----------------------------
-// blockDim.x >= cap; one workgroup per listed cell; buffer holds x, y, z triples in send-cell-list order
-__global__
-void LoadPositionBuffer(double* __restrict__ buf, const int* __restrict__ list, const int* __restrict__ offsets,
-                        const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
-                        const int* __restrict__ nAtoms, int cap, double sx, double sy, double sz, int nCells, int boundAtoms, int* __restrict__ status)
-{
-   if (boundAtoms > 0 && offsets[nCells] > boundAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
-   const int c = list[blockIdx.x];
-   if ((int)threadIdx.x < nAtoms[c]) {
-      const size_t s = (size_t)c * cap + threadIdx.x;
-      double* o = buf + 3 * (size_t)(offsets[blockIdx.x] + threadIdx.x);
-      o[0] = rx[s] + sx; o[1] = ry[s] + sy; o[2] = rz[s] + sz;
-   }
-}
-
-__global__
-void UnloadPositionBuffer(const double* __restrict__ buf, const int* __restrict__ list, const int* __restrict__ offsets,
-                          double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
-                          const int* __restrict__ nAtoms, int cap)
-{
-   const int c = list[blockIdx.x];
-   if ((int)threadIdx.x < nAtoms[c]) {
-      const size_t s = (size_t)c * cap + threadIdx.x;
-      const double* o = buf + 3 * (size_t)(offsets[blockIdx.x] + threadIdx.x);
-      rx[s] = o[0]; ry[s] = o[1]; rz[s] = o[2];
-   }
-}
-
 // ====================================================================================================================
 // LJ at 5 sigma: ~730 listed neighbours per atom.  Gathering them from global memory is address-rate bound (one lane address per
 // clock per CU: 5.8 ms per step at 80^3, slower than the cell kernel), so the list is split into NL_GROUPS groups of 9 stencil

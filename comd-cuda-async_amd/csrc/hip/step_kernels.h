@@ -54,6 +54,26 @@ void AdvanceVelocityPosition(double* __restrict__ rx, double* __restrict__ ry, d
    rx[tid] += dtDrift * x * invMass; ry[tid] += dtDrift * y * invMass; rz[tid] += dtDrift * z * invMass;
 }
 
+// second half kick of one step + first half kick and drift of the next, one pass (same operations, same order, as AdvanceVelocity followed
+// by AdvanceVelocityPosition: the two kicks stay two roundings)
+__global__ __launch_bounds__(256)
+void AdvanceVelocityVelocityPosition(double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
+                                     double* __restrict__ px, double* __restrict__ py, double* __restrict__ pz,
+                                     const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
+                                     const int* __restrict__ iSpecies, const double* __restrict__ speciesMass,
+                                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double dtKick1, double dtKick2, double dtDrift)
+{
+   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int c = (int)(tid / cap);
+   if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
+   const double invMass = 1.0 / speciesMass[iSpecies[tid]];
+   const double gx = fx[tid], gy = fy[tid], gz = fz[tid];
+   double x = px[tid] + dtKick1 * gx, y = py[tid] + dtKick1 * gy, z = pz[tid] + dtKick1 * gz;
+   x += dtKick2 * gx; y += dtKick2 * gy; z += dtKick2 * gz;
+   px[tid] = x; py[tid] = y; pz[tid] = z;
+   rx[tid] += dtDrift * x * invMass; ry[tid] += dtDrift * y * invMass; rz[tid] += dtDrift * z * invMass;
+}
+
 // ---- energy: stage 1 = per-block partial sums in a fixed order, stage 2 = one block adds the partials --------
 __global__ __launch_bounds__(256)
 void ReduceEnergyPartial(const double* __restrict__ e, const double* __restrict__ px, const double* __restrict__ py,
@@ -197,66 +217,33 @@ void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restri
    if (lane == 0) { nAtoms[c] = live; dirty[c] = 0; }
 }
 
-// ---- exclusive scan of nAtoms over a cell list (gpu_kernels.cu:357-407 fill + scan) ---------------------
-// single workgroup of 1024 threads; out[i] = sum_{k<i} nAtoms[list[k]], out[n] = total; also copied to *total.
-__global__ __launch_bounds__(1024)
-void ScanCellCounts(const int* __restrict__ nAtoms, const int* __restrict__ list, int n, int* __restrict__ out, int* __restrict__ total)
-{
-   __shared__ int sWave[16];
-   __shared__ int sCarry;
-   if (threadIdx.x == 0) sCarry = 0;
-   __syncthreads();
-   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   for (int base = 0; base < n; base += 1024) {
-      const int i = base + threadIdx.x;
-      const int v = i < n ? nAtoms[list ? list[i] : i] : 0;
-      int incl = v;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-      if (lane == 63) sWave[wave] = incl;
-      __syncthreads();
-      int wavePrefix = 0;
-      for (int w = 0; w < wave; ++w) wavePrefix += sWave[w];
-      const int carry = sCarry;
-      if (i < n) out[i] = carry + wavePrefix + incl - v;
-      __syncthreads();
-      if (threadIdx.x == 1023) sCarry = carry + wavePrefix + incl;
-      __syncthreads();
-   }
-   if (threadIdx.x == 0) { out[n] = sCarry; if (total) *total = sCarry; }
-}
-
-// several independent scans in one launch: workgroup b serves job b (the twelve send/receive lists of the force exchange)
-struct ScanJobs { const int* list[12]; int n[12]; int* out[12]; };
+// ---- exclusive scan of nAtoms over cell lists (gpu_kernels.cu:357-407 fill + scan) -----------------------------
+// Workgroup b serves job b: out[i] = sum_{k<i} nAtoms[list[k]], out[n] = total (also copied to *total when given: the count header of
+// an atom message).  One pass: each of the 1024 threads sums a run of consecutive cells, one block scan orders the runs, the
+// thread rewrites its run.  (Round 1 walked the list 1024 cells at a time behind three barriers each: 15 us for a face of 7200 cells.)
+struct ScanJobs { const int* list[12]; int n[12]; int* out[12]; int* total[12]; };
 
 __global__ __launch_bounds__(1024)
 void ScanCellCountsBatch(const int* __restrict__ nAtoms, ScanJobs jobs)
 {
    __shared__ int sWave[16];
-   __shared__ int sCarry;
    const int* __restrict__ list = jobs.list[blockIdx.x];
    const int n = jobs.n[blockIdx.x];
    int* __restrict__ out = jobs.out[blockIdx.x];
-   if (threadIdx.x == 0) sCarry = 0;
-   __syncthreads();
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   for (int base = 0; base < n; base += 1024) {
-      const int i = base + threadIdx.x;
-      const int v = i < n ? nAtoms[list[i]] : 0;
-      int incl = v;
+   const int run = (n + 1023) >> 10;
+   const int lo = threadIdx.x * run, hi = lo + run < n ? lo + run : n;
+   int mine = 0;
+   for (int i = lo; i < hi; ++i) mine += nAtoms[list ? list[i] : i];
+   int incl = mine;
 #pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-      if (lane == 63) sWave[wave] = incl;
-      __syncthreads();
-      int wavePrefix = 0;
-      for (int w = 0; w < wave; ++w) wavePrefix += sWave[w];
-      const int carry = sCarry;
-      if (i < n) out[i] = carry + wavePrefix + incl - v;
-      __syncthreads();
-      if (threadIdx.x == 1023) sCarry = carry + wavePrefix + incl;
-      __syncthreads();
-   }
-   if (threadIdx.x == 0) out[n] = sCarry;
+   for (int d = 1; d < 64; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+   if (lane == 63) sWave[wave] = incl;
+   __syncthreads();
+   int before = incl - mine;
+   for (int w = 0; w < wave; ++w) before += sWave[w];
+   for (int i = lo; i < hi; ++i) { out[i] = before; before += nAtoms[list ? list[i] : i]; }
+   if (threadIdx.x == 1023) { out[n] = before; if (jobs.total[blockIdx.x]) *jobs.total[blockIdx.x] = before; }
 }
 
 // four message counts of an axis phase -> pinned host memory (read by the host one step later, behind an event)
@@ -270,35 +257,43 @@ __global__ void MirrorCounts(const int* __restrict__ d0, const int* __restrict__
 }
 
 // ---- atom halo message -----------------------------------------------------------------------------------
+// Both faces of an axis phase are packed by ONE launch and unpacked by one (blockIdx.y = face of the pair): half the launches of a
+// step that is, on one rank, a string of 5-microsecond kernels.
+struct AtomPackJob { char* msg; const int* list; const int* offsets; int nCells; double sx, sy, sz; int capacityAtoms; };
+
 // gpu_redistribute.h:376-402 LoadAtomsBufferPacked: one workgroup per listed cell gathers its atoms into the SoA
 // message at offsets[cell]; positions are shifted across the periodic boundary.  blockDim.x >= cap.
 __global__
-void LoadAtomsBufferPacked(char* __restrict__ msg, const int* __restrict__ list, const int* __restrict__ offsets,
-                           int nCells, AtomArrays at, const int* __restrict__ nAtoms, int cap,
-                           double sx, double sy, double sz, int capacityAtoms, int* __restrict__ status)
+void LoadAtomsBufferPacked(AtomPackJob j0, AtomPackJob j1, AtomArrays at, const int* __restrict__ nAtoms, int cap, int* __restrict__ status)
 {
-   const int c = list[blockIdx.x];
+   const AtomPackJob& jb = blockIdx.y ? j1 : j0;
+   if ((int)blockIdx.x >= jb.nCells) return;
+   const int c = jb.list[blockIdx.x];
    const int t = threadIdx.x;
-   const int n = offsets[nCells];
-   if (n > capacityAtoms) { if (blockIdx.x == 0 && t == 0) atomicOr(&status[2], 1); return; }
+   const int n = jb.offsets[jb.nCells];
+   if (n > jb.capacityAtoms) { if (blockIdx.x == 0 && t == 0) atomicOr(&status[2], 1); return; }
    if (t >= nAtoms[c]) return;
    const size_t o = (size_t)c * cap + t;
-   const int d = offsets[blockIdx.x] + t;
-   int* mg = (int*)(msg + COMD_ATOM_MSG_HEADER);
+   const int d = jb.offsets[blockIdx.x] + t;
+   int* mg = (int*)(jb.msg + COMD_ATOM_MSG_HEADER);
    int* mt = mg + n;
    double* m = (double*)(mt + n);
    mg[d] = at.gid[o]; mt[d] = at.spec[o];
-   m[d] = at.rx[o] + sx; m[n + d] = at.ry[o] + sy; m[2*(size_t)n + d] = at.rz[o] + sz;
+   m[d] = at.rx[o] + jb.sx; m[n + d] = at.ry[o] + jb.sy; m[2*(size_t)n + d] = at.rz[o] + jb.sz;
    m[3*(size_t)n + d] = at.px[o]; m[4*(size_t)n + d] = at.py[o]; m[5*(size_t)n + d] = at.pz[o];
 }
 
+struct AtomUnpackJob { const char* msg; int nBuf, capacityAtoms; };
+
 // gpu_redistribute.h:499-620: every received atom finds its cell from its coordinates and is appended there.
 __global__ __launch_bounds__(256)
-void UnloadAtomsBufferPacked(const char* __restrict__ msg, int nBuf, int capacityAtoms, AtomArrays at, int* __restrict__ nAtoms,
+void UnloadAtomsBufferPacked(AtomUnpackJob j0, AtomUnpackJob j1, AtomArrays at, int* __restrict__ nAtoms,
                              int* __restrict__ dirty, int* __restrict__ status, LinkCellGpu boxes, int cap)
 {
-   const int n = nBuf >= 0 ? nBuf : ((const int*)msg)[0];
-   if (n < 0 || n > capacityAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
+   const AtomUnpackJob& jb = blockIdx.y ? j1 : j0;
+   const char* __restrict__ msg = jb.msg;
+   const int n = jb.nBuf >= 0 ? jb.nBuf : ((const int*)msg)[0];
+   if (n < 0 || n > jb.capacityAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i >= n) return;
    const int* mg = (const int*)(msg + COMD_ATOM_MSG_HEADER);
@@ -330,22 +325,56 @@ void UnloadAtomsBufferPacked(const char* __restrict__ msg, int nBuf, int capacit
    dirty[c] = 1;
 }
 
-// ---- EAM force (dfEmbed) halo message: gpu_redistribute.h:638-672 ---------------------------------------------
-// blockDim.x >= cap; one workgroup per listed cell; positional (both sides hold the cell in gid order).
+// ---- EAM force (dfEmbed) and position halo messages: gpu_redistribute.h:638-672 ------------------------------
+// blockDim.x >= cap; one workgroup per listed cell; positional (both sides hold the cell in gid order); blockIdx.y = face of the pair.
 // boundAtoms > 0: the size both ends of the message agreed on beforehand; more atoms than that cannot be sent -> status[2]
+struct SlotJob { double* buf; const int* list; const int* offsets; int nCells; int boundAtoms; double sx, sy, sz; };
+
 __global__
-void LoadForceBuffer(double* __restrict__ buf, const int* __restrict__ list, const int* __restrict__ offsets,
-                     const double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap, int nCells, int boundAtoms, int* __restrict__ status)
+void LoadForceBuffer(SlotJob j0, SlotJob j1, const double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap, int* __restrict__ status)
 {
-   if (boundAtoms > 0 && offsets[nCells] > boundAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
-   const int c = list[blockIdx.x];
-   if ((int)threadIdx.x < nAtoms[c]) buf[offsets[blockIdx.x] + threadIdx.x] = dfEmbed[(size_t)c * cap + threadIdx.x];
+   const SlotJob& jb = blockIdx.y ? j1 : j0;
+   if ((int)blockIdx.x >= jb.nCells) return;
+   if (jb.boundAtoms > 0 && jb.offsets[jb.nCells] > jb.boundAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
+   const int c = jb.list[blockIdx.x];
+   if ((int)threadIdx.x < nAtoms[c]) jb.buf[jb.offsets[blockIdx.x] + threadIdx.x] = dfEmbed[(size_t)c * cap + threadIdx.x];
 }
 
 __global__
-void UnloadForceBuffer(const double* __restrict__ buf, const int* __restrict__ list, const int* __restrict__ offsets,
-                       double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap)
+void UnloadForceBuffer(SlotJob j0, SlotJob j1, double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap)
 {
-   const int c = list[blockIdx.x];
-   if ((int)threadIdx.x < nAtoms[c]) dfEmbed[(size_t)c * cap + threadIdx.x] = buf[offsets[blockIdx.x] + threadIdx.x];
+   const SlotJob& jb = blockIdx.y ? j1 : j0;
+   if ((int)blockIdx.x >= jb.nCells) return;
+   const int c = jb.list[blockIdx.x];
+   if ((int)threadIdx.x < nAtoms[c]) dfEmbed[(size_t)c * cap + threadIdx.x] = jb.buf[jb.offsets[blockIdx.x] + threadIdx.x];
+}
+
+// positional refresh of the halo copies between list builds (slot order == the sender's slot order); x, y, z triples in send-cell-list order
+__global__
+void LoadPositionBuffer(SlotJob j0, SlotJob j1, const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
+                        const int* __restrict__ nAtoms, int cap, int* __restrict__ status)
+{
+   const SlotJob& jb = blockIdx.y ? j1 : j0;
+   if ((int)blockIdx.x >= jb.nCells) return;
+   if (jb.boundAtoms > 0 && jb.offsets[jb.nCells] > jb.boundAtoms) { if (blockIdx.x == 0 && threadIdx.x == 0) atomicOr(&status[2], 1); return; }
+   const int c = jb.list[blockIdx.x];
+   if ((int)threadIdx.x < nAtoms[c]) {
+      const size_t s = (size_t)c * cap + threadIdx.x;
+      double* o = jb.buf + 3 * (size_t)(jb.offsets[blockIdx.x] + threadIdx.x);
+      o[0] = rx[s] + jb.sx; o[1] = ry[s] + jb.sy; o[2] = rz[s] + jb.sz;
+   }
+}
+
+__global__
+void UnloadPositionBuffer(SlotJob j0, SlotJob j1, double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
+                          const int* __restrict__ nAtoms, int cap)
+{
+   const SlotJob& jb = blockIdx.y ? j1 : j0;
+   if ((int)blockIdx.x >= jb.nCells) return;
+   const int c = jb.list[blockIdx.x];
+   if ((int)threadIdx.x < nAtoms[c]) {
+      const size_t s = (size_t)c * cap + threadIdx.x;
+      const double* o = jb.buf + 3 * (size_t)(jb.offsets[blockIdx.x] + threadIdx.x);
+      rx[s] = o[0]; ry[s] = o[1]; rz[s] = o[2];
+   }
 }

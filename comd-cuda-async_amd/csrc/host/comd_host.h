@@ -176,6 +176,9 @@ typedef struct HaloExchangeSt {
    /* optional: both messages of an axis phase behind one synchronisation */
    void (*msgBytes2)(void* parms, void* data, int faceM, char* bufM, int faceP, char* bufP, int out[2]);
    void (*unloadBuffer)(void* parms, void* data, int face, int bufSize, char* buf);
+   /* optional: both faces of an axis phase packed / unpacked by one device launch each (same results as two loadBuffer / unloadBuffer calls) */
+   void (*loadBuffer2)(void* parms, void* data, int faceM, char* bufM, int faceP, char* bufP, int nBytes[2]);
+   void (*unloadBuffer2)(void* parms, void* data, int faceA, int bufSizeA, char* bufA, int faceB, int bufSizeB, char* bufB);
    void (*destroy)(void* parms);
    void* parms;
    int type;                              /* 0 atoms, 1 force, 2 positions */
@@ -197,6 +200,7 @@ typedef struct AtomExchangeParmsSt {
    int* cellList[6];                      /* host */
    int* cellListGpu[6];                   /* device */
    int* d_cellOffsets;                    /* device scratch, max nCells + 1 */
+   int* d_cellOffsets2;                   /* second scratch: the two faces of an axis phase are scanned and packed together */
    real_t shift[6][3];                    /* pbcFactor * globalExtent */
    int capacityAtoms;
    int sendBound[6], recvBound[6];        /* agreed message sizes in atoms, 0 = none (capacityAtoms applies) */

@@ -129,6 +129,33 @@ static void unloadAtomsBuffer(void* vparms, void* data, int face, int bufSize, c
    unloadAtomsBufferToGpu(buf, nBuf, bound, &sim->gpu, sim->gpu.boundary_stream);
 }
 
+static void loadAtomsBuffer2(void* vparms, void* data, int faceM, char* bufM, int faceP, char* bufP, int nBytes[2])
+{
+   AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
+   SimFlat* sim = (SimFlat*)data;
+   const int f[2] = { faceM, faceP };
+   int nCells[2], caps[2]; int* lists[2]; int* offs[2] = { parms->d_cellOffsets, parms->d_cellOffsets2 };
+   for (int k = 0; k < 2; ++k) {
+      nCells[k] = parms->nCells[f[k]]; lists[k] = parms->cellListGpu[f[k]];
+      caps[k] = parms->sendBound[f[k]] > 0 && parms->sendBound[f[k]] < parms->capacityAtoms ? parms->sendBound[f[k]] : parms->capacityAtoms;
+   }
+   compactCellsGpu2(bufM, bufP, nCells, lists, &sim->gpu, offs, parms->shift[faceM], parms->shift[faceP], caps, sim->gpu.boundary_stream);
+   nBytes[0] = nBytes[1] = -1;              /* counts stay on the device (message headers) */
+}
+
+static void unloadAtomsBuffer2(void* vparms, void* data, int faceA, int bufSizeA, char* bufA, int faceB, int bufSizeB, char* bufB)
+{
+   AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
+   SimFlat* sim = (SimFlat*)data;
+   const int f[2] = { faceA, faceB }, size[2] = { bufSizeA, bufSizeB };
+   int nBuf[2], bound[2];
+   for (int k = 0; k < 2; ++k) {
+      nBuf[k] = size[k] < 0 ? -1 : (size[k] - COMD_ATOM_MSG_HEADER) / COMD_ATOM_MSG_BYTES_PER_ATOM;
+      bound[k] = nBuf[k] < 0 && parms->recvBound[f[k]] > 0 && parms->recvBound[f[k]] < parms->capacityAtoms ? parms->recvBound[f[k]] : parms->capacityAtoms;
+   }
+   unloadAtomsBufferToGpu2(bufA, nBuf[0], bound[0], bufB, nBuf[1], bound[1], &sim->gpu, sim->gpu.boundary_stream);
+}
+
 static void atomsCountPtrs(void* vparms, HaloExchange* hh, int faceM, int faceP, const int* out[4])
 {
    (void)vparms; (void)faceM; (void)faceP;         /* the counts sit in the message headers */
@@ -145,7 +172,7 @@ static void destroyAtomsExchange(void* vparms)
 {
    AtomExchangeParms* parms = (AtomExchangeParms*)vparms;
    for (int f = 0; f < 6; ++f) { free(parms->cellList[f]); comdDeviceFree(parms->cellListGpu[f]); }
-   comdDeviceFree(parms->d_cellOffsets);
+   comdDeviceFree(parms->d_cellOffsets); comdDeviceFree(parms->d_cellOffsets2);
 }
 
 HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice)
@@ -178,6 +205,8 @@ HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDev
    if (allocDevice) {
       for (int f = 0; f < 6; ++f) parms->cellListGpu[f] = uploadInts(parms->cellList[f], parms->nCells[f]);
       parms->d_cellOffsets = (int*)comdDeviceMalloc((long)(2 * maxSize + 1) * sizeof(int));
+      parms->d_cellOffsets2 = (int*)comdDeviceMalloc((long)(2 * maxSize + 1) * sizeof(int));
+      hh->loadBuffer2 = loadAtomsBuffer2; hh->unloadBuffer2 = unloadAtomsBuffer2;
       hh->sendBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->sendBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
       hh->recvBufM = (char*)comdDeviceMalloc(hh->bufCapacity); hh->recvBufP = (char*)comdDeviceMalloc(hh->bufCapacity);
    }
@@ -193,6 +222,34 @@ static int loadForceBuffer(void* vparms, void* vdata, int face, char* buf)
    loadForceBufferFromGpu((real_t*)buf, parms->nCells[face], parms->sendCellsGpu[face], parms->sendOffsetsGpu[face], &s->gpu, s->gpu.boundary_stream);
    s->gpu.msgBoundAtoms = 0;
    return -1;
+}
+
+static void loadSlotBuffer2(void* vparms, void* vdata, int faceM, char* bufM, int faceP, char* bufP, int nBytes[2])
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
+   const int f[2] = { faceM, faceP };
+   int nCells[2], bounds[2]; int* lists[2]; int* offs[2];
+   for (int k = 0; k < 2; ++k) { nCells[k] = parms->nCells[f[k]]; lists[k] = parms->sendCellsGpu[f[k]]; offs[k] = parms->sendOffsetsGpu[f[k]]; bounds[k] = parms->sendBound[f[k]]; }
+   if (parms->positions) {
+      loadPositionBufferFromGpu2((real_t*)bufM, (real_t*)bufP, nCells, lists, offs, bounds, parms->shift[faceM], parms->shift[faceP], &s->gpu, s->gpu.boundary_stream);
+      nBytes[0] = parms->msgBytesCached[faceM]; nBytes[1] = parms->msgBytesCached[faceP];
+   } else {
+      loadForceBufferFromGpu2((real_t*)bufM, (real_t*)bufP, nCells, lists, offs, bounds, &s->gpu, s->gpu.boundary_stream);
+      nBytes[0] = nBytes[1] = -1;
+   }
+}
+
+static void unloadSlotBuffer2(void* vparms, void* vdata, int faceA, int bufSizeA, char* bufA, int faceB, int bufSizeB, char* bufB)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)vparms;
+   SimFlat* s = (SimFlat*)vdata;
+   (void)bufSizeA; (void)bufSizeB;         /* positional */
+   const int f[2] = { faceA, faceB };
+   int nCells[2]; int* lists[2]; int* offs[2];
+   for (int k = 0; k < 2; ++k) { nCells[k] = parms->nCells[f[k]]; lists[k] = parms->recvCellsGpu[f[k]]; offs[k] = parms->recvOffsetsGpu[f[k]]; }
+   if (parms->positions) unloadPositionBufferToGpu2((const real_t*)bufA, (const real_t*)bufB, nCells, lists, offs, &s->gpu, s->gpu.boundary_stream);
+   else                  unloadForceBufferToGpu2((const real_t*)bufA, (const real_t*)bufB, nCells, lists, offs, &s->gpu, s->gpu.boundary_stream);
 }
 
 /* force and position messages: the counts are the totals of the batched scan (send lists: what leaves; receive lists: what must arrive) */
@@ -274,6 +331,7 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
    hh->deviceBuffers = allocDevice;
    hh->msgHeaderBytes = 0; hh->msgBytesPerAtom = (int)sizeof(real_t); hh->capacityAtoms = parms->capacityAtoms;
    hh->countPtrs = forceCountPtrs; hh->setBounds = forceSetBounds;
+   if (allocDevice) { hh->loadBuffer2 = loadSlotBuffer2; hh->unloadBuffer2 = unloadSlotBuffer2; }
    if (allocDevice) {
       for (int f = 0; f < 6; ++f) {
          parms->sendCellsGpu[f] = uploadInts(parms->sendCells[f], parms->nCells[f]);
@@ -357,6 +415,7 @@ HaloExchange* initPositionHaloExchange(Domain* domain, LinkCell* boxes, int allo
    hh->deviceBuffers = allocDevice;
    hh->msgHeaderBytes = 0; hh->msgBytesPerAtom = 3 * (int)sizeof(real_t); hh->capacityAtoms = parms->capacityAtoms;
    hh->countPtrs = forceCountPtrs; hh->setBounds = forceSetBounds;
+   if (allocDevice) { hh->loadBuffer2 = loadSlotBuffer2; hh->unloadBuffer2 = unloadSlotBuffer2; }
    hh->exactCounts = 1;                      /* slots are frozen between list builds: the counts of the first exchange hold until the next build */
    if (allocDevice) {
       for (int f = 0; f < 6; ++f) {
@@ -441,14 +500,24 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
       for (int i = 0; i < 4; ++i) bound[i] = hh->exactCounts ? sp->mirror[i] : boundOf(sp->mirror[i], hh->capacityAtoms);
       if (hh->setBounds) { hh->setBounds(hh->parms, faceM, bound[0], bound[3]); hh->setBounds(hh->parms, faceP, bound[1], bound[2]); }
    }
-   int nSendM = hh->loadBuffer(hh->parms, data, faceM, hh->sendBufM);
-   int nSendP = hh->loadBuffer(hh->parms, data, faceP, hh->sendBufP);
+   int nSendM, nSendP;
+   if (hh->loadBuffer2) {                                  /* both faces: one scan launch, one pack launch */
+      int n[2];
+      hh->loadBuffer2(hh->parms, data, faceM, hh->sendBufM, faceP, hh->sendBufP, n);
+      nSendM = n[0]; nSendP = n[1];
+   } else {
+      nSendM = hh->loadBuffer(hh->parms, data, faceM, hh->sendBufM);
+      nSendP = hh->loadBuffer(hh->parms, data, faceP, hh->sendBufP);
+   }
 
    if (selfOnly) {
       /* this rank is its own neighbour along the axis: what it sends through the minus face arrives through its plus
        * face.  Unpack straight from the send buffers (the reference's comm path has the same shortcut, haloExchange.c:788-853). */
-      hh->unloadBuffer(hh->parms, data, faceM, nSendP, hh->sendBufP);
-      hh->unloadBuffer(hh->parms, data, faceP, nSendM, hh->sendBufM);
+      if (hh->unloadBuffer2) hh->unloadBuffer2(hh->parms, data, faceM, nSendP, hh->sendBufP, faceP, nSendM, hh->sendBufM);
+      else {
+         hh->unloadBuffer(hh->parms, data, faceM, nSendP, hh->sendBufP);
+         hh->unloadBuffer(hh->parms, data, faceP, nSendM, hh->sendBufM);
+      }
       return;
    }
    if (useSized) {
@@ -457,8 +526,11 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
       const int h = hh->msgHeaderBytes, b = hh->msgBytesPerAtom;
       sendReceiveDevice2Sized(hh->sendBufM, h + bound[0] * b, nbrM, hh->recvBufP, h + bound[2] * b,
                               hh->sendBufP, h + bound[1] * b, nbrP, hh->recvBufM, h + bound[3] * b, sim->gpu.boundary_stream);
-      hh->unloadBuffer(hh->parms, data, faceM, -1, hh->recvBufM);
-      hh->unloadBuffer(hh->parms, data, faceP, -1, hh->recvBufP);
+      if (hh->unloadBuffer2) hh->unloadBuffer2(hh->parms, data, faceM, -1, hh->recvBufM, faceP, -1, hh->recvBufP);
+      else {
+         hh->unloadBuffer(hh->parms, data, faceM, -1, hh->recvBufM);
+         hh->unloadBuffer(hh->parms, data, faceP, -1, hh->recvBufP);
+      }
       if (hh->setBounds) { hh->setBounds(hh->parms, faceM, 0, 0); hh->setBounds(hh->parms, faceP, 0, 0); }
    } else {
       if (nSendM < 0 && nSendP < 0 && hh->msgBytes2) {
@@ -479,8 +551,11 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
          nRecvP = sendReceiveParallel(hh->sendBufM, nSendM, nbrM, hh->recvBufP, hh->bufCapacity, nbrP);
          nRecvM = sendReceiveParallel(hh->sendBufP, nSendP, nbrP, hh->recvBufM, hh->bufCapacity, nbrM);
       }
-      hh->unloadBuffer(hh->parms, data, faceM, nRecvM, hh->recvBufM);
-      hh->unloadBuffer(hh->parms, data, faceP, nRecvP, hh->recvBufP);
+      if (hh->unloadBuffer2) hh->unloadBuffer2(hh->parms, data, faceM, nRecvM, hh->recvBufM, faceP, nRecvP, hh->recvBufP);
+      else {
+         hh->unloadBuffer(hh->parms, data, faceM, nRecvM, hh->recvBufM);
+         hh->unloadBuffer(hh->parms, data, faceP, nRecvP, hh->recvBufP);
+      }
    }
    if (sized && !(hh->exactCounts && useSized)) {
       /* leave the four counts of this phase where the next exchange of the axis finds them without asking the device */

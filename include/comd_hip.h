@@ -257,6 +257,9 @@ void advancePositionGpu(SimGpu* sim, real_t dt);
 /* the first half kick and the drift of a step in one pass over the atoms: bit-identical to advanceVelocityGpu(dtKick)
  * followed by advancePositionGpu(dtDrift) (timestep.c:52-58), one launch and one sweep over p fewer */
 void advanceVelocityPositionGpu(SimGpu* sim, real_t dtKick, real_t dtDrift);
+/* the second half kick of a step and the first half kick + drift of the next in one pass: bit-identical to advanceVelocityGpu(dtKick1)
+ * followed by advanceVelocityPositionGpu(dtKick2, dtDrift) */
+void advanceVelocityVelocityPositionGpu(SimGpu* sim, real_t dtKick1, real_t dtKick2, real_t dtDrift);
 /* computeEnergy(SimFlat*, real_t eLocal[2]), gpu_kernels.cu:1045-1059: {sum e, sum p^2/2m} of local atoms.
  * Deterministic two-stage reduction (the reference uses fp64 atomics). Blocks until the result is on the host. */
 void computeEnergy(SimGpu* sim, real_t* eLocal);
@@ -288,6 +291,11 @@ void getAtomMsgSoAPtr(char* buffer, AtomMsgSoA* atomMsg, int n);
  * the call does not block; the count is in the message header.  capacityAtoms bounds the message. */
 void compactCellsGpu(char* work_d, int nCells, int* d_cellList, SimGpu* sim, int* d_cellOffsets,
                      const real_t shift[3], int capacityAtoms, comdStream_t stream);
+/* Both faces of an axis phase (index 0 = minus, 1 = plus) with one scan launch and one pack launch / one unpack launch -- the halo
+ * driver's path; the single-face entry points above are these with one face.  workP / msgB / bufP == NULL: one face. */
+void compactCellsGpu2(char* workM, char* workP, const int nCells[2], int* const d_cellList[2], SimGpu* sim, int* const d_cellOffsets[2],
+                      const real_t shiftM[3], const real_t shiftP[3], const int capacityAtoms[2], comdStream_t stream);
+void unloadAtomsBufferToGpu2(const char* msgA, int nBufA, int maxAtomsA, const char* msgB, int nBufB, int maxAtomsB, SimGpu* sim, comdStream_t stream);
 /* blocking read of a device message's atom count (the reference returns it from compactCellsGpu, :534-535) */
 int  atomMsgCountGpu(SimGpu* sim, const char* msg_d, comdStream_t stream);
 /* unloadAtomsBufferToGpu(buf, nBuf, SimFlat*, gpu_buf, stream), gpu_kernels.cu:572-617: bin every atom of the device
@@ -300,6 +308,10 @@ void unloadAtomsBufferToGpu(const char* msg_d, int nBuf, int maxAtomsInMsg, SimG
 void loadForceBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream);
 /* unloadForceBufferToGpu(buf, nBuf, nCells, cellList, natoms_buf, partial_sums, SimFlat*, gpu_buf, stream), :642-660 */
 void unloadForceBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream);
+void loadForceBufferFromGpu2(real_t* bufM, real_t* bufP, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
+                             const int boundAtoms[2], SimGpu* sim, comdStream_t stream);
+void unloadForceBufferToGpu2(const real_t* bufA, const real_t* bufB, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
+                             SimGpu* sim, comdStream_t stream);
 /* The force exchange scans twelve cell lists per step (natoms_buf/partial_sums of haloExchange.c:438-465).  Occupancies are final
  * once the atom exchange has been sorted, so all of them can be scanned in ONE launch: scanCellListsGpu fills d_cellOffsets[i]
  * (nCells[i] + 1 ints) for up to 12 lists; comdForceScansReady(1) then tells load/unloadForceBuffer*Gpu to use those offsets as they are. */
@@ -395,6 +407,10 @@ void comm_finalize(void);
  * reference re-sends whole atoms and finds their slots through a gid hash table (haloExchange.c:1622-1700, hashTable.c). */
 void loadPositionBufferFromGpu(real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, const real_t shift[3], SimGpu* sim, comdStream_t stream);
 void unloadPositionBufferToGpu(const real_t* gpu_buf, int nCells, int* d_cellList, int* d_cellOffsets, SimGpu* sim, comdStream_t stream);
+void loadPositionBufferFromGpu2(real_t* bufM, real_t* bufP, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
+                                const int boundAtoms[2], const real_t shiftM[3], const real_t shiftP[3], SimGpu* sim, comdStream_t stream);
+void unloadPositionBufferToGpu2(const real_t* bufA, const real_t* bufB, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
+                                SimGpu* sim, comdStream_t stream);
 
 /* ---- device-side timing for bench.py -------------------------------------------------------- */
 /* HIP-event pair on a stream: comdEventCreate/Record/ElapsedMs.  Used to time kernels on the stream they
