@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the other force methods (reported as `variants` at N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--precision", choices=["double", "single"], default="double",
+                    help="single: the PRECISION=single build (real_t = float); never the headline -- the default run reports it as a variant")
     ap.add_argument("--allow-host-staged", action="store_true",
                     help="N > 1 only: if the RCCL communicator cannot be formed, run over host-staged gloo messages instead of failing "
                          "(the line then carries \"measured\": false -- it is a functional rehearsal, not an xGMI number)")
@@ -122,6 +124,12 @@ def measured_traffic(pot, method, nx):
 
 def main():
     a = parse()
+    os.environ["COMD_PRECISION"] = a.precision               # read by the binding when it picks lib*.so / lib*_sp.so: one precision per process
+    global FP64_VECTOR_PEAK_TFLOPS
+    if a.precision == "single":                                # half the bytes per real_t field (species stays an int), the fp32 vector peak
+        FORCE_BYTES.update(lj=28.0, eam=88.0)
+        STEP_BYTES.update(lj=28.0 + 112.0, eam=88.0 + 112.0)
+        FP64_VECTOR_PEAK_TFLOPS = 157.3
     method = a.method or ("thread_atom" if a.pot == "lj" else "cta_cell")
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -240,9 +248,9 @@ def main():
         out = {
             "metric": "atom_updates_per_sec", "value": value, "unit": "atom-updates/s",
             "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64" if a.precision == "double" else "f32", "data": "synthetic",
             "config": {"workload": f"{a.pot.upper()} Cu FCC {a.nx}^3 unit cells per GPU ({int(n_local)} atoms/GPU, {n_global} total), "
-                                   f"{method} kernel, fp64, T=600 K, dt=1 fs",
+                                   f"{method} kernel, {'fp64' if a.precision == 'double' else 'fp32 (PRECISION=single build)'}, T=600 K, dt=1 fs",
                        "decomposition": f"{px}x{py}x{pz}", "halo_overlap": bool(use_async), "cell_capacity": m["cap"],
                        **({"transport": transport_name or ("rccl-loopback" if loopback else "rccl")} if a.gpus > 1 or loopback else {})},
             "per_gpu_value": value / a.gpus,
@@ -254,7 +262,7 @@ def main():
                          "kernel_ms_per_step": force_per_step_ms, "launches_timed": m["launches"],
                          "algorithmic_bytes_per_atom": FORCE_BYTES[a.pot],
                          "whole_step_achieved_GBs": STEP_BYTES[a.pot] * value / a.gpus / 1e9,
-                         "fp64_vector": {"achieved_TFLOPs": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 if force_ms > 0 else None,
+                         ("fp64_vector" if a.precision == "double" else "fp32_vector"): {"achieved_TFLOPs": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 if force_ms > 0 else None,
                                          "peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "flop_per_atom": flop,
                                          "frac": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if force_ms > 0 else None},
                          "note": "fp64 ALU-bound stencil: ~4000 (LJ) / ~283 (EAM) candidate pairs per atom against 56 / 176 algorithmic bytes (SURVEY.md 8d)"},
@@ -276,6 +284,20 @@ def main():
                              "ms_per_step": 1e3 * v["elapsed"] / a.steps, "force_ms_per_step": v["force_ms"] / a.steps,
                              "energy_per_atom_eV": (v["ep"] + v["ek"]) / v["n_global"], "cell_capacity": v["cap"],
                              **({"neighbor_list_builds_timed": v["nl_builds"]} if meth.endswith(("_nl", "_pairlist")) else {})})
+    # the single-precision build on the two BASELINE workloads: a child process each (the two builds export the same symbols)
+    if a.gpus == 1 and not a.no_variants and a.precision == "double":
+        import subprocess
+        for pot in ("lj", "eam"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--precision", "single", "--pot", pot, "--steps", str(a.steps), "--warmup", str(a.warmup),
+                   "--nx", str(a.nx), "--no-variants", "--no-cpu-baseline"]
+            try:
+                child = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                v = json.loads(child.stdout.strip().splitlines()[-1])
+                variants.append({"workload": v["config"]["workload"], "dtype": "f32", "value": v["value"], "ms_per_step": v["ms_per_step"],
+                                 "force_ms_per_step": v["roofline"]["kernel_ms_per_step"], "energy_per_atom_eV": v["energy_per_atom_eV"],
+                                 "cell_capacity": v["config"]["cell_capacity"]})
+            except Exception as exc:                          # a variant line must never take the headline down with it
+                variants.append({"workload": f"{pot.upper()} Cu FCC {a.nx}^3, PRECISION=single build", "dtype": "f32", "error": repr(exc)[:200]})
     if rank == 0:
         if variants:
             out["variants"] = variants

@@ -18,11 +18,20 @@ POT_DIR = os.path.join(REPO_ROOT, "pots")
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int_p = ctypes.POINTER(ctypes.c_int)
 
+# One build per precision (make PRECISION=single -> lib*_sp.so, real_t = float: the reference's DOUBLE_PRECISION = OFF, mytype.h:8-21).
+# A process binds ONE of them: COMD_PRECISION=single selects the float build before the first library is loaded.
+PRECISION = os.environ.get("COMD_PRECISION", "double")
+if PRECISION not in ("double", "single"):
+    raise ImportError(f"COMD_PRECISION={PRECISION!r}: expected 'double' or 'single'")
+_SFX = "_sp" if PRECISION == "single" else ""
+c_real = ctypes.c_float if PRECISION == "single" else ctypes.c_double
+c_real_p = ctypes.POINTER(c_real)
+
 
 class HostAtoms(ctypes.Structure):
     """include/comd_hip.h HostAtoms"""
     _fields_ = [("nAtoms", c_int_p), ("gid", c_int_p), ("iSpecies", c_int_p)] + \
-               [(n, c_double_p) for n in ("rx", "ry", "rz", "px", "py", "pz", "fx", "fy", "fz", "e")]
+               [(n, c_real_p) for n in ("rx", "ry", "rz", "px", "py", "pz", "fx", "fy", "fz", "e")]
 
 
 SENDRECV_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int,
@@ -55,7 +64,7 @@ def _load(name):
         return _libs[name]
     path = os.path.join(_CSRC, name)
     if not os.path.exists(path):
-        raise ImportError(f"{path} is missing: build it with `make -C {_CSRC}` (hipcc --offload-arch=gfx950). "
+        raise ImportError(f"{path} is missing: build it with `make -C {_CSRC}{' PRECISION=single' if _SFX else ''}` (hipcc --offload-arch=gfx950). "
                           "There is no CPU fallback for the product path.")
     _libs[name] = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     return _libs[name]
@@ -63,7 +72,7 @@ def _load(name):
 
 def lib_hip():
     """libcomd_hip.so: HIP kernels + C-ABI launch wrappers."""
-    lib = _load("libcomd_hip.so")
+    lib = _load(f"libcomd_hip{_SFX}.so")
     if not getattr(lib, "_typed", False):
         lib.SetupGpu.argtypes = [ctypes.c_int] * 3
         lib.SetupGpu.restype = ctypes.c_int
@@ -91,7 +100,7 @@ def lib_hip():
 def lib_host():
     """libcomd_host.so: the C host (CLI, decomposition, link cells, potentials, halo exchange, time step)."""
     lib_hip()
-    lib = _load("libcomd_host.so")
+    lib = _load(f"libcomd_host{_SFX}.so")
     if not getattr(lib, "_typed", False):
         vp = ctypes.c_void_p
         lib.comdCreate.restype = vp
@@ -123,7 +132,7 @@ def lib_host():
         lib.comdPutAtomInBox.argtypes = [vp, ctypes.c_int, ctypes.c_int, c_double_p, c_double_p]
         lib.comdGatherByGid.argtypes = [vp, ctypes.c_int, c_double_p]
         lib.comdScatterByGid.argtypes = [vp, ctypes.c_int, c_double_p]
-        lib.timestep.argtypes = [vp, ctypes.c_int, ctypes.c_double]
+        lib.timestep.argtypes = [vp, ctypes.c_int, c_real]
         lib.timestep.restype = ctypes.c_double
         for fn in ("redistributeAtoms", "computeForce", "kineticEnergyGpu", "sumAtoms"):
             getattr(lib, fn).argtypes = [vp]
@@ -442,10 +451,10 @@ class GlooTransport:
 
     def _allreduce(self, ctx, buf, count, dtype):
         np, torch, dist = self.np, self.torch, self.dist
-        ctype = ctypes.c_double if dtype == 1 else ctypes.c_int
+        ctype = ctypes.c_double if dtype == 1 else ctypes.c_float if dtype == 3 else ctypes.c_int
         arr = np.ctypeslib.as_array(ctypes.cast(buf, ctypes.POINTER(ctype)), shape=(count,))
         t = torch.from_numpy(arr.copy())
-        if dtype == 1 and self.world > 2:
+        if dtype in (1, 3) and self.world > 2:
             # floating-point sums in RANK ORDER (gather, then add 0, 1, 2, ...): the result does not depend on gloo's reduction tree, so
             # runs are reproducible and comparable bit for bit with a serial sum over the ranks (what the tests' checker does)
             parts = [torch.empty_like(t) for _ in range(self.world)]

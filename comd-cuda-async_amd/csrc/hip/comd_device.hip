@@ -439,7 +439,7 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       (void)nlView(sim);
       NlSlabView v; v.list = n->list16; v.count = n->nNeighbors; v.rows = n->slabRows;
       const int threads = ((n->maxCellAtoms + 63) / 64) * 64;
-      const size_t lds = (size_t)3 * n->maxSlabAtoms * sizeof(double);
+      const size_t lds = (size_t)3 * n->maxSlabAtoms * sizeof(real_t);
       static size_t attrSet = 0;
       if (lds > attrSet) {
          HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_nl_slabs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -832,7 +832,7 @@ extern "C" void scanCellListsGpu(SimGpu* sim, int nLists, int** d_cellLists, con
 
 static SlotJob slotJob(const real_t* buf, int nCells, int* list, int* offsets, int bound, const real_t* shift)
 {
-   SlotJob j; j.buf = (double*)buf; j.list = list; j.offsets = offsets; j.nCells = nCells; j.boundAtoms = bound;
+   SlotJob j; j.buf = (real_t*)buf; j.list = list; j.offsets = offsets; j.nCells = nCells; j.boundAtoms = bound;
    j.sx = shift ? shift[0] : 0.0; j.sy = shift ? shift[1] : 0.0; j.sz = shift ? shift[2] : 0.0;
    return j;
 }
@@ -944,7 +944,7 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
          int stencilCap = n->nBuilds > 0 && n->maxSlabAtoms > 0 ? n->maxSlabAtoms + n->maxSlabAtoms / 4 + 16 : worst;
          if (stencilCap > worst) stencilCap = worst;
          for (;;) {
-            const size_t lds = (size_t)EAM_NL_WAVES * (3 * (size_t)stencilCap + 32 + (16 * (size_t)n->slabRows * 2 + 7) / 8) * sizeof(double);
+            const size_t lds = (size_t)EAM_NL_WAVES * eamBuildWaveBytes(stencilCap, n->slabRows);
             static size_t attrSet = 0;
             if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)BuildNeighborListCell16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
             HIP_CHECK(hipMemsetAsync(n->stats, 0, 2 * sizeof(int), st));
@@ -965,7 +965,7 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
       } else
       {
          // one workgroup per cell, a thread per slot; the LDS holds a whole group of full cells (<= 9 * 512 atoms = 108 KB)
-         const size_t lds = (size_t)3 * NL_GROUP_CELLS * sim->maxAtoms * sizeof(double);
+         const size_t lds = (size_t)3 * NL_GROUP_CELLS * sim->maxAtoms * sizeof(real_t);
          static size_t attrSet = 0;
          if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)BuildNeighborListSlabs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
          hipLaunchKernelGGL(BuildNeighborListSlabs, dim3(sim->boxes.nLocalBoxes), dim3(sim->maxAtoms), lds, st,

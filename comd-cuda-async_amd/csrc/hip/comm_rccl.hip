@@ -94,10 +94,10 @@ static void rcclSendrecv2Sized(void*, const void* sendM, int nSendM, int dstM, v
 
 static void rcclAllreduce(void*, void* buf, int count, int dtype)
 {
-   const size_t bytes = (size_t)count * (dtype == 1 ? sizeof(double) : sizeof(int));
+   const size_t bytes = (size_t)count * (dtype == 1 ? sizeof(double) : dtype == 3 ? sizeof(float) : sizeof(int));
    if (bytes > kScratchBytes) { fprintf(stderr, "Rank %d: allreduce of %zu bytes exceeds the scratch buffer\n", g_rank, bytes); exit(-1); }
    HIPC(hipMemcpyAsync(g_dScratch, buf, bytes, hipMemcpyHostToDevice, g_stream));
-   NCCLC(ncclAllReduce(g_dScratch, g_dScratch, (size_t)count, dtype == 1 ? ncclDouble : ncclInt, dtype == 2 ? ncclMax : ncclSum, g_comm, g_stream));
+   NCCLC(ncclAllReduce(g_dScratch, g_dScratch, (size_t)count, dtype == 1 ? ncclDouble : dtype == 3 ? ncclFloat : ncclInt, dtype == 2 ? ncclMax : ncclSum, g_comm, g_stream));
    HIPC(hipMemcpyAsync(buf, g_dScratch, bytes, hipMemcpyDeviceToHost, g_stream));
    HIPC(hipStreamSynchronize(g_stream));
 }

@@ -1,4 +1,4 @@
-// device_common.h -- wave64 helpers shared by the gfx950 kernels.
+// device_common.h -- wave64 helpers shared by the gfx950 kernels, in the precision of the build (real_t).
 //
 // Stands where the reference's gpu_common.h does (interpolate :48-86, warp_reduce :252-278,
 // PTX laneid/bfi :231-236/:316-321), re-expressed for CDNA4: 64-lane wavefronts, DPP/bpermute
@@ -15,8 +15,18 @@ __device__ __forceinline__ int laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, 
 
 __device__ __forceinline__ int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
 
-// 1/x to fp64 round-off: v_rcp_f64 is good to ~2^-24 relative, two Newton steps square that twice.
-__device__ __forceinline__ double rcp64(double x)
+// Literals and vector types of the build's precision (comd_hip.h real_t): every floating constant in the kernels goes through R(),
+// so the single-precision build does pure fp32 arithmetic (a bare 0.5 would drag the expression into fp64).
+#define R(x) ((real_t)(x))
+#ifdef COMD_SINGLE
+typedef float2 real2;
+#else
+typedef double2 real2;
+#endif
+#define FAR_AWAY R(1.0e15)                  // padding coordinate: never inside a cutoff, its square still finite in fp32
+
+// 1/x to round-off.  fp64: v_rcp_f64 is good to ~2^-23 relative, two Newton steps square that twice; fp32: v_rcp_f32 (1 ulp) + one step.
+__device__ __forceinline__ double rcpR(double x)
 {
    double y = __builtin_amdgcn_rcp(x);
    double e = __builtin_fma(-x, y, 1.0);
@@ -25,9 +35,15 @@ __device__ __forceinline__ double rcp64(double x)
    y = __builtin_fma(y, e, y);
    return y;
 }
+__device__ __forceinline__ float rcpR(float x)
+{
+   float y = __builtin_amdgcn_rcpf(x);
+   const float e = __builtin_fmaf(-x, y, 1.0f);
+   return __builtin_fmaf(y, e, y);
+}
 
-// 1/sqrt(x) to fp64 round-off from v_rsq_f64 (~2^-24) with two Newton steps.
-__device__ __forceinline__ double rsqrt64(double x)
+// 1/sqrt(x) to round-off from v_rsq_f64 (~2^-23) with two Newton steps / v_rsq_f32 with one.
+__device__ __forceinline__ double rsqrtR(double x)
 {
    double y = __builtin_amdgcn_rsq(x);
    double h = 0.5 * x;
@@ -35,41 +51,65 @@ __device__ __forceinline__ double rsqrt64(double x)
    y = y * __builtin_fma(-h * y, y, 1.5);
    return y;
 }
+__device__ __forceinline__ float rsqrtR(float x)
+{
+   float y = __builtin_amdgcn_rsqf(x);
+   const float h = 0.5f * x;
+   return y * __builtin_fmaf(-h * y, y, 1.5f);
+}
 
-// 64-bit cross-lane read through ds_bpermute (two dword permutes); srcLane in [0,63].
-__device__ __forceinline__ double bpermute64(double v, int srcLane)
+__device__ __forceinline__ double fmaR(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float  fmaR(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double floorR(double x) { return __builtin_floor(x); }
+__device__ __forceinline__ float  floorR(float x) { return __builtin_floorf(x); }
+__device__ __forceinline__ double minR(double a, double b) { return __builtin_fmin(a, b); }
+__device__ __forceinline__ float  minR(float a, float b) { return __builtin_fminf(a, b); }
+__device__ __forceinline__ double maxR(double a, double b) { return __builtin_fmax(a, b); }
+__device__ __forceinline__ float  maxR(float a, float b) { return __builtin_fmaxf(a, b); }
+
+// cross-lane read through ds_bpermute (one dword permute per 32 bits); srcLane in [0,63].
+__device__ __forceinline__ double bpermuteR(double v, int srcLane)
 {
    int lo = __double2loint(v), hi = __double2hiint(v);
    lo = __builtin_amdgcn_ds_bpermute(srcLane << 2, lo);
    hi = __builtin_amdgcn_ds_bpermute(srcLane << 2, hi);
    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float bpermuteR(float v, int srcLane)
+{
+   return __int_as_float(__builtin_amdgcn_ds_bpermute(srcLane << 2, __float_as_int(v)));
+}
 
 // butterfly sum over the 64 lanes; every lane ends with the total, in a fixed order
-__device__ __forceinline__ double waveSum(double v)
+__device__ __forceinline__ real_t waveSum(real_t v)
 {
 #pragma unroll
-   for (int m = 32; m >= 1; m >>= 1) v += bpermute64(v, laneId() ^ m);
+   for (int m = 32; m >= 1; m >>= 1) v += bpermuteR(v, laneId() ^ m);
    return v;
 }
 
 // ---- DPP / permlane reductions: pure VALU, no trip through the LDS crossbar --------------------------------------
 // dpp_ctrl encodings (gfx9): quad_perm 0x00-0xFF, row_ror:n 0x120+n, row_bcast:15 0x142, row_bcast:31 0x143
 template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dppMove64(double v)       // lanes not written by the DPP pattern receive 0.0
+__device__ __forceinline__ double dppMoveR(double v)        // lanes not written by the DPP pattern receive 0.0
 {
    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
    return __hiloint2double(hi, lo);
 }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dppMoveR(float v)
+{
+   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
 
 // sum within each row of 16 lanes; every lane of the row ends with the row total
-__device__ __forceinline__ double rowSum(double v)
+__device__ __forceinline__ real_t rowSum(real_t v)
 {
-   v += dppMove64<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
-   v += dppMove64<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
-   v += dppMove64<0x124, 0xF>(v);      // row_ror:4
-   v += dppMove64<0x128, 0xF>(v);      // row_ror:8
+   v += dppMoveR<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
+   v += dppMoveR<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
+   v += dppMoveR<0x124, 0xF>(v);       // row_ror:4
+   v += dppMoveR<0x128, 0xF>(v);       // row_ror:8
    return v;
 }
 
@@ -82,7 +122,15 @@ __device__ __forceinline__ double pairSum(double pa, double pb)
    auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(pa), (unsigned)__double2hiint(pb), false, false);
    double v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
    v = rowSum(v);
-   v += dppMove64<0x142, 0xA>(v);      // row_bcast:15 into rows 1 and 3
+   v += dppMoveR<0x142, 0xA>(v);       // row_bcast:15 into rows 1 and 3
+   return v;
+}
+__device__ __forceinline__ float pairSum(float pa, float pb)
+{
+   auto w = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(pa), (unsigned)__float_as_int(pb), false, false);
+   float v = __int_as_float((int)w[0]) + __int_as_float((int)w[1]);
+   v = rowSum(v);
+   v += dppMoveR<0x142, 0xA>(v);
    return v;
 }
 
@@ -105,56 +153,56 @@ __device__ __forceinline__ int xcdRemap(int bid, int nBlocks)
 
 // Quadratic table interpolation, value + derivative (reference gpu_common.h:48-86; host eam.c:557-579).
 // `v` points at the padded table: v[0] is the leading pad, v[i+1] is sample i.
-struct TableView { const double* v; double x0, xn, invDx, invDxHalf, invDxXx0; };
+struct TableView { const real_t* v; real_t x0, xn, invDx, invDxHalf, invDxXx0; };
 
-__device__ __forceinline__ TableView makeTable(const InterpolationObjectGpu& t, const double* values)
+__device__ __forceinline__ TableView makeTable(const InterpolationObjectGpu& t, const real_t* values)
 {
    TableView tv; tv.v = values; tv.x0 = t.x0; tv.xn = t.xn; tv.invDx = t.invDx; tv.invDxHalf = t.invDxHalf; tv.invDxXx0 = t.invDxXx0;
    return tv;
 }
 
-__device__ __forceinline__ void interpolate(const TableView& t, double r, double& f, double& df)
+__device__ __forceinline__ void interpolate(const TableView& t, real_t r, real_t& f, real_t& df)
 {
-   r = fmax(r, t.x0);
-   r = fmin(r, t.xn);
+   r = maxR(r, t.x0);
+   r = minR(r, t.xn);
    r = r * t.invDx - t.invDxXx0;
-   double ri = floor(r);
+   real_t ri = floorR(r);
    int ii = (int)ri;
    r -= ri;
-   double v0 = t.v[ii], v1 = t.v[ii + 1], v2 = t.v[ii + 2], v3 = t.v[ii + 3];
-   double g1 = v2 - v0, g2 = v3 - v1;
-   f  = v1 + 0.5 * r * (g1 + r * (v2 + v0 - 2.0 * v1));
+   real_t v0 = t.v[ii], v1 = t.v[ii + 1], v2 = t.v[ii + 2], v3 = t.v[ii + 3];
+   real_t g1 = v2 - v0, g2 = v3 - v1;
+   f  = v1 + R(0.5) * r * (g1 + r * (v2 + v0 - R(2.0) * v1));
    df = (g1 + r * (g2 - g1)) * t.invDxHalf;
 }
 
 // phi(r) and rho(r) tabulated on the SAME grid (funcfl files are): values interleaved {phi_i, rho_i} so one index
 // computation and four 16-byte LDS reads serve both interpolations.  v[2*i], v[2*i+1]; i = 0 is the leading pad.
-__device__ __forceinline__ void interpolatePair(const double* __restrict__ v, const TableView& t, double r,
-                                                double& phi, double& dphi, double& rho, double& drho)
+__device__ __forceinline__ void interpolatePair(const real_t* __restrict__ v, const TableView& t, real_t r,
+                                                real_t& phi, real_t& dphi, real_t& rho, real_t& drho)
 {
-   r = fmax(r, t.x0);
-   r = fmin(r, t.xn);
+   r = maxR(r, t.x0);
+   r = minR(r, t.xn);
    r = r * t.invDx - t.invDxXx0;
-   const double ri = floor(r);
+   const real_t ri = floorR(r);
    const int ii = (int)ri;
    r -= ri;
-   const double2* __restrict__ q = reinterpret_cast<const double2*>(v) + ii;
-   const double2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+   const real2* __restrict__ q = reinterpret_cast<const real2*>(v) + ii;
+   const real2 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
    {
-      const double g1 = a2.x - a0.x, g2 = a3.x - a1.x;
-      phi  = a1.x + 0.5 * r * (g1 + r * (a2.x + a0.x - 2.0 * a1.x));
+      const real_t g1 = a2.x - a0.x, g2 = a3.x - a1.x;
+      phi  = a1.x + R(0.5) * r * (g1 + r * (a2.x + a0.x - R(2.0) * a1.x));
       dphi = (g1 + r * (g2 - g1)) * t.invDxHalf;
    }
    {
-      const double g1 = a2.y - a0.y, g2 = a3.y - a1.y;
-      rho  = a1.y + 0.5 * r * (g1 + r * (a2.y + a0.y - 2.0 * a1.y));
+      const real_t g1 = a2.y - a0.y, g2 = a3.y - a1.y;
+      rho  = a1.y + R(0.5) * r * (g1 + r * (a2.y + a0.y - R(2.0) * a1.y));
       drho = (g1 + r * (g2 - g1)) * t.invDxHalf;
    }
 }
 
 // Cubic spline in r^2 (reference gpu_common.h:95-129): value f(r) and (1/r) df/dr -- no square root on the path except the
 // single-precision one that picks the table interval.
-__device__ __forceinline__ void interpolateSpline(const InterpolationSplineObjectGpu& t, double r2, double& f, double& df)
+__device__ __forceinline__ void interpolateSpline(const InterpolationSplineObjectGpu& t, real_t r2, real_t& f, real_t& df)
 {
    float r = __builtin_sqrtf((float)r2);
    r = fmaxf(r, t.x0);
@@ -162,11 +210,11 @@ __device__ __forceinline__ void interpolateSpline(const InterpolationSplineObjec
    r = r * t.invDx - t.invDxXx0;
    int ii = (int)floorf(r);
    ii = ii < t.n - 1 ? ii : t.n - 1;                          // r == xn lands on the last interval
-   const double* __restrict__ c = t.coefficients + 4 * ii;
-   const double a = c[0], b = c[1], cc = c[2], d = c[3];
-   const double tmp = a * r2 + b;
+   const real_t* __restrict__ c = t.coefficients + 4 * ii;
+   const real_t a = c[0], b = c[1], cc = c[2], d = c[3];
+   const real_t tmp = a * r2 + b;
    f = (tmp * r2 + cc) * r2 + d;
-   df = 2.0 * ((3.0 * tmp - b) * r2 + cc);
+   df = R(2.0) * ((R(3.0) * tmp - b) * r2 + cc);
 }
 
 __device__ __forceinline__ CellGeom makeGeom(const LinkCellGpu& b)

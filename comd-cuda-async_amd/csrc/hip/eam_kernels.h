@@ -15,14 +15,14 @@
 #include "device_common.h"
 
 struct EamArgs {
-   const double* __restrict__ rx; const double* __restrict__ ry; const double* __restrict__ rz;
-   double* __restrict__ fx; double* __restrict__ fy; double* __restrict__ fz; double* __restrict__ e;
-   double* __restrict__ rhobar; double* __restrict__ dfEmbed;
+   const real_t* __restrict__ rx; const real_t* __restrict__ ry; const real_t* __restrict__ rz;
+   real_t* __restrict__ fx; real_t* __restrict__ fy; real_t* __restrict__ fz; real_t* __restrict__ e;
+   real_t* __restrict__ rhobar; real_t* __restrict__ dfEmbed;
    const int* __restrict__ nAtoms;
    const int* __restrict__ nbr;
    const int* __restrict__ cells;
    int nCells, cap;
-   double rc2;
+   real_t rc2;
    InterpolationObjectGpu phi, rho, f;
    InterpolationSplineObjectGpu phiS, rhoS;
 };
@@ -38,9 +38,9 @@ __global__ __launch_bounds__(256)
 void EAM_Force_thread_atom(EamArgs a, int lanesPerCell)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-   double* sRho = (double*)ldsRaw;
+   real_t* sRho = (real_t*)ldsRaw;
    const int nRhoPad = a.rho.n + 3;
-   double* sPhi = sRho + nRhoPad;
+   real_t* sPhi = sRho + nRhoPad;
    const bool sameGrid = (STEP == 1) && LDS_TABLES && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
    if (LDS_TABLES) {
       if (sameGrid) {
@@ -67,26 +67,26 @@ void EAM_Force_thread_atom(EamArgs a, int lanesPerCell)
       const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
       for (int ia = l; ia < ni; ia += lanesPerCell) {
          const size_t iOff = (size_t)iBox * a.cap + ia;
-         const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
-         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0, dfi = 0.0;
+         const real_t xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+         real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0), dfi = R(0.0);
          if (STEP == 3) { fx = a.fx[iOff]; fy = a.fy[iOff]; fz = a.fz[iOff]; dfi = a.dfEmbed[iOff]; }
          for (int k = 0; k < 27; ++k) {
             const int jBox = nb[k];
             const int nj = a.nAtoms[jBox];
             const size_t base = (size_t)jBox * a.cap;
             for (int j = 0; j < nj; ++j) {
-               const double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
-               const double r2 = dx*dx + dy*dy + dz*dz;
-               if (r2 <= a.rc2 && r2 > 0.0) {
-                  double rho, drho, dphi;
+               const real_t dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
+               const real_t r2 = dx*dx + dy*dy + dz*dz;
+               if (r2 <= a.rc2 && r2 > R(0.0)) {
+                  real_t rho, drho, dphi;
                   if (SPLINE) {                                  // drho, dphi are (1/r) d/dr already
                      interpolateSpline(a.rhoS, r2, rho, drho);
-                     if (STEP == 1) { double phi; interpolateSpline(a.phiS, r2, phi, dphi); e += phi; rb += rho; }
+                     if (STEP == 1) { real_t phi; interpolateSpline(a.phiS, r2, phi, dphi); e += phi; rb += rho; }
                      else           { dphi = (dfi + a.dfEmbed[base + j]) * drho; }
                   } else {
-                     const double ir = rsqrt64(r2), r = r2 * ir;
+                     const real_t ir = rsqrtR(r2), r = r2 * ir;
                      if (STEP == 1) {
-                        double phi;
+                        real_t phi;
                         if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
                         else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
                         e += phi; rb += rho;
@@ -101,7 +101,7 @@ void EAM_Force_thread_atom(EamArgs a, int lanesPerCell)
             }
          }
          a.fx[iOff] = fx; a.fy[iOff] = fy; a.fz[iOff] = fz;
-         if (STEP == 1) { a.e[iOff] = 0.5 * e; a.rhobar[iOff] = rb; }
+         if (STEP == 1) { a.e[iOff] = R(0.5) * e; a.rhobar[iOff] = rb; }
       }
    }
 }
@@ -118,7 +118,7 @@ void EAM_Force_embed(EamArgs a)
    if (ia >= a.nAtoms[iBox]) return;
    const size_t iOff = (size_t)iBox * a.cap + ia;
    const TableView fT = makeTable(a.f, a.f.values);
-   double F, dF;
+   real_t F, dF;
    interpolate(fT, a.rhobar[iOff], F, dF);
    a.dfEmbed[iOff] = dF;
    a.e[iOff] += F;
@@ -134,26 +134,26 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
    const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
    for (int i = lane; i < ni; i += 64) {
       const size_t iOff = (size_t)iBox * a.cap + i;
-      const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
-      double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0, dfi = 0.0;
+      const real_t xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+      real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0), dfi = R(0.0);
       if (STEP == 3) { fx = a.fx[iOff]; fy = a.fy[iOff]; fz = a.fz[iOff]; dfi = a.dfEmbed[iOff]; }
       for (int k = 0; k < 27; ++k) {
          const int jBox = nb[k];
          const int nj = a.nAtoms[jBox];
          const size_t base = (size_t)jBox * a.cap;
          for (int j = 0; j < nj; ++j) {
-            const double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
-            const double r2 = dx*dx + dy*dy + dz*dz;
-            if (r2 <= a.rc2 && r2 > 0.0) {
-               double rho, drho, dphi;
+            const real_t dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
+            const real_t r2 = dx*dx + dy*dy + dz*dz;
+            if (r2 <= a.rc2 && r2 > R(0.0)) {
+               real_t rho, drho, dphi;
                if (SPLINE) {
                   interpolateSpline(a.rhoS, r2, rho, drho);
-                  if (STEP == 1) { double phi; interpolateSpline(a.phiS, r2, phi, dphi); e += phi; rb += rho; }
+                  if (STEP == 1) { real_t phi; interpolateSpline(a.phiS, r2, phi, dphi); e += phi; rb += rho; }
                   else           { dphi = (dfi + a.dfEmbed[base + j]) * drho; }
                } else {
-                  const double ir = rsqrt64(r2), r = r2 * ir;
+                  const real_t ir = rsqrtR(r2), r = r2 * ir;
                   if (STEP == 1) {
-                     double phi;
+                     real_t phi;
                      if (sameGrid) interpolatePair(rhoT.v, rhoT, r, phi, dphi, rho, drho);
                      else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
                      e += phi; rb += rho;
@@ -168,8 +168,8 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
          }
       }
       a.fx[iOff] = fx; a.fy[iOff] = fy; a.fz[iOff] = fz;
-      if (STEP == 1) { a.e[iOff] = 0.5 * e; a.rhobar[iOff] = rb; }
+      if (STEP == 1) { a.e[iOff] = R(0.5) * e; a.rhobar[iOff] = rb; }
    }
 }
 
-static inline size_t eamCtaTableBytes(int step, int nRho, int nPhi) { return (size_t)(nRho + 3 + (step == 1 ? nPhi + 3 : 0)) * 8; }
+static inline size_t eamCtaTableBytes(int step, int nRho, int nPhi) { return (size_t)(nRho + 3 + (step == 1 ? nPhi + 3 : 0)) * sizeof(real_t); }

@@ -15,56 +15,56 @@
 #include "device_common.h"
 
 struct LjArgs {
-   const double* __restrict__ rx; const double* __restrict__ ry; const double* __restrict__ rz;
-   double* __restrict__ fx; double* __restrict__ fy; double* __restrict__ fz; double* __restrict__ e;
+   const real_t* __restrict__ rx; const real_t* __restrict__ ry; const real_t* __restrict__ rz;
+   real_t* __restrict__ fx; real_t* __restrict__ fy; real_t* __restrict__ fz; real_t* __restrict__ e;
    const int* __restrict__ nAtoms;
    const int* __restrict__ nbr;        // [nLocal*27], self first
    const int* __restrict__ cells;      // optional cell list
    int nCells, cap;
-   double rc2, s6, eShift, eps;
+   real_t rc2, s6, eShift, eps;
 };
 
 // One accepted pair.  With u = s6 / r^6:  e_pair = u (u - 1) - eShift,  f_pair = 24 u (2u - 1) / r^2 * d.
 // The constant factors (24 eps on the force, 4 eps * 1/2 on the energy) are applied once per atom by the caller.
 // ENERGY = false drops the energy ops: e[] is only consumed by computeEnergy, i.e. by the last step of a timestep() call.
 template <bool ENERGY>
-__device__ __forceinline__ void ljPair(double dx, double dy, double dz, double r2, const LjArgs& a,
-                                       double& fx, double& fy, double& fz, double& e)
+__device__ __forceinline__ void ljPair(real_t dx, real_t dy, real_t dz, real_t r2, const LjArgs& a,
+                                       real_t& fx, real_t& fy, real_t& fz, real_t& e)
 {
-   const double ir2 = rcp64(r2);
-   const double u = a.s6 * ir2 * ir2 * ir2;
-   if (ENERGY) e += __builtin_fma(u, u - 1.0, -a.eShift);
-   const double fr = u * ir2 * __builtin_fma(u, 2.0, -1.0);
-   fx = __builtin_fma(fr, dx, fx); fy = __builtin_fma(fr, dy, fy); fz = __builtin_fma(fr, dz, fz);
+   const real_t ir2 = rcpR(r2);
+   const real_t u = a.s6 * ir2 * ir2 * ir2;
+   if (ENERGY) e += fmaR(u, u - R(1.0), -a.eShift);
+   const real_t fr = u * ir2 * fmaR(u, R(2.0), -R(1.0));
+   fx = fmaR(fr, dx, fx); fy = fmaR(fr, dy, fy); fz = fmaR(fr, dz, fz);
 }
 
 // one neighbour cell against the wave's 64 i atoms; SELF adds the r2 > 0 guard of the own cell
 template <bool SELF, bool ENERGY>
-__device__ __forceinline__ void ljCellLoop(const LjArgs& a, int jBox, double xi, double yi, double zi,
-                                           double& fx, double& fy, double& fz, double& e)
+__device__ __forceinline__ void ljCellLoop(const LjArgs& a, int jBox, real_t xi, real_t yi, real_t zi,
+                                           real_t& fx, real_t& fy, real_t& fz, real_t& e)
 {
    const int nj = uniform(a.nAtoms[jBox]);
-   const double* __restrict__ px = a.rx + (size_t)jBox * a.cap;
-   const double* __restrict__ py = a.ry + (size_t)jBox * a.cap;
-   const double* __restrict__ pz = a.rz + (size_t)jBox * a.cap;
+   const real_t* __restrict__ px = a.rx + (size_t)jBox * a.cap;
+   const real_t* __restrict__ py = a.ry + (size_t)jBox * a.cap;
+   const real_t* __restrict__ pz = a.rz + (size_t)jBox * a.cap;
    // j is wave-uniform: fetch 8 neighbours per scalar-load batch (3 x s_load_dwordx16), then test them
    int j = 0;
    for (; j + 8 <= nj; j += 8) {
-      double xs[8], ys[8], zs[8];
+      real_t xs[8], ys[8], zs[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) { xs[u] = px[j + u]; ys[u] = py[j + u]; zs[u] = pz[j + u]; }
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
-         double dx = xi - xs[u], dy = yi - ys[u], dz = zi - zs[u];
-         double r2 = dx*dx + dy*dy + dz*dz;
-         bool hit = SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2);
+         real_t dx = xi - xs[u], dy = yi - ys[u], dz = zi - zs[u];
+         real_t r2 = dx*dx + dy*dy + dz*dz;
+         bool hit = SELF ? (r2 <= a.rc2 && r2 > R(0.0)) : (r2 <= a.rc2);
          if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
       }
    }
    for (; j < nj; ++j) {
-      double dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
-      double r2 = dx*dx + dy*dy + dz*dz;
-      bool hit = SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2);
+      real_t dx = xi - px[j], dy = yi - py[j], dz = zi - pz[j];
+      real_t r2 = dx*dx + dy*dy + dz*dz;
+      bool hit = SELF ? (r2 <= a.rc2 && r2 > R(0.0)) : (r2 <= a.rc2);
       if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
    }
 }
@@ -84,8 +84,8 @@ __device__ __forceinline__ void ljChunkGeneric(const LjArgs& a, int iBox, int ni
    const int g = lane / m, ai = lane - g * m;
    const bool valid = g < G;
    const size_t iOff = (size_t)iBox * a.cap + chunk * 64 + (valid ? ai : 0);
-   const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
-   double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+   const real_t xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+   real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0);
    for (int t = 0; t * G < 27; ++t) {
       const int k = t * G + g;
       const bool okk = valid && k < 27;
@@ -94,22 +94,22 @@ __device__ __forceinline__ void ljChunkGeneric(const LjArgs& a, int iBox, int ni
       const size_t base = (size_t)jBox * a.cap;
       for (int j = 0; __any(j < nj); ++j) {
          if (j < nj) {
-            const double dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
-            const double r2 = dx*dx + dy*dy + dz*dz;
-            if (r2 <= a.rc2 && r2 > 0.0) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+            const real_t dx = xi - a.rx[base + j], dy = yi - a.ry[base + j], dz = zi - a.rz[base + j];
+            const real_t r2 = dx*dx + dy*dy + dz*dz;
+            if (r2 <= a.rc2 && r2 > R(0.0)) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
          }
       }
    }
-   double tx = fx, ty = fy, tz = fz, te = e;
+   real_t tx = fx, ty = fy, tz = fz, te = e;
    for (int r = 1; r < G; ++r) {                       // all lanes take part; only lanes < m keep the result
       const int src = (ai + r * m) & 63;
-      tx += bpermute64(fx, src); ty += bpermute64(fy, src); tz += bpermute64(fz, src);
-      if (ENERGY) te += bpermute64(e, src);
+      tx += bpermuteR(fx, src); ty += bpermuteR(fy, src); tz += bpermuteR(fz, src);
+      if (ENERGY) te += bpermuteR(e, src);
    }
    if (lane < m) {
-      const double fs = 24.0 * a.eps;
+      const real_t fs = R(24.0) * a.eps;
       a.fx[iOff] = tx * fs; a.fy[iOff] = ty * fs; a.fz[iOff] = tz * fs;
-      if (ENERGY) a.e[iOff] = te * 2.0 * a.eps;
+      if (ENERGY) a.e[iOff] = te * R(2.0) * a.eps;
    }
 }
 
@@ -141,16 +141,16 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
       const int iSlot = chunk * 64 + lane;
       const bool active = iSlot < ni;
       const size_t iOff = (size_t)iBox * a.cap + (active ? iSlot : ni - 1);   // idle lanes shadow the last atom
-      const double xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
-      double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+      const real_t xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+      real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0);
       // (a software-pipelined variant -- scalar loads of batch b+1 issued before batch b is evaluated, 4 neighbours per batch to fit
       // two batches in SGPRs -- measured 9 % slower: 4.30 vs 3.95 ms; the 8-wide batches below rely on the other waves for latency cover)
       ljCellLoop<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
       for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
       if (active) {
-         const double fs = 24.0 * a.eps;
+         const real_t fs = R(24.0) * a.eps;
          a.fx[iOff] = fx * fs; a.fy[iOff] = fy * fs; a.fz[iOff] = fz * fs;
-         if (ENERGY) a.e[iOff] = e * 2.0 * a.eps;          // 4 eps * 1/2 per pair
+         if (ENERGY) a.e[iOff] = e * R(2.0) * a.eps;          // 4 eps * 1/2 per pair
       }
    }
    // NOTE: no store may precede the scalar-path loads above on any path through this kernel, or the compiler gives up proving the
@@ -166,7 +166,7 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
 // a CU; the reference stages 128 atoms at a time behind two barriers per tile, here a slab costs two barriers per ~440 atoms.
 // Inside a slab every lane walks the same j sequence, so each ds_read_b128 (two neighbours per read) is a broadcast.
 #define LJ_CTA_CELLS     3                 // stencil cells staged per slab: 27 / 3 = 9 slabs, 13 KB of LDS -> the CU fills up with workgroups
-static inline size_t ljCtaLdsBytes(int cap) { return (size_t)3 * (LJ_CTA_CELLS * cap + 8) * 8 + 16 * 4; }   // slab capacity = LJ_CTA_CELLS * cap atoms
+static inline size_t ljCtaLdsBytes(int cap) { return (size_t)3 * (LJ_CTA_CELLS * cap + 8) * sizeof(real_t) + 16 * 4; }   // slab capacity = LJ_CTA_CELLS * cap atoms
 
 // Pairlists (-L; the reference's LJ_Force_cta_cell_pairlist, gpu_lj_cta_cell.h:124-274): one bit per (wave, 8-neighbour trip) says
 // whether ANY atom of the wave is within cutoff + skin of ANY of the trip's eight neighbours.  The bits are generated by the force
@@ -175,14 +175,14 @@ static inline size_t ljCtaLdsBytes(int cap) { return (size_t)3 * (LJ_CTA_CELLS *
 // words[((cell * wavesMax + wave) * LJ_CTA_SLABS + slab) * LJ_PL_WORDS + trip/32]
 #define LJ_CTA_SLABS 9
 #define LJ_PL_WORDS  8                     // 256 trips = 2048 staged atoms per slab at most (3 cells of <= 512)
-struct LjPairlist { unsigned* __restrict__ words; int wavesMax; double plCut2; };
+struct LjPairlist { unsigned* __restrict__ words; int wavesMax; real_t plCut2; };
 
 // all lanes read the same neighbour pair (LDS broadcast); NA = atoms per thread
 template <int NA, int PL, bool SELF, bool ENERGY>
-__device__ __forceinline__ void slabLoop(const double* sx, const double* sy, const double* sz, int nSlab, const LjArgs& a,
-                                         const double (&xi)[2], const double (&yi)[2], const double (&zi)[2],
-                                         double (&fx)[2], double (&fy)[2], double (&fz)[2], double (&e)[2],
-                                         unsigned* __restrict__ plWords, double plCut2, const bool (&own)[2])
+__device__ __forceinline__ void slabLoop(const real_t* sx, const real_t* sy, const real_t* sz, int nSlab, const LjArgs& a,
+                                         const real_t (&xi)[2], const real_t (&yi)[2], const real_t (&zi)[2],
+                                         real_t (&fx)[2], real_t (&fy)[2], real_t (&fz)[2], real_t (&e)[2],
+                                         unsigned* __restrict__ plWords, real_t plCut2, const bool (&own)[2])
 {
    // eight neighbours per trip: the twelve 16-byte LDS reads are issued together, then evaluated (the slab is padded to a multiple of 8)
    unsigned word = 0;
@@ -192,12 +192,12 @@ __device__ __forceinline__ void slabLoop(const double* sx, const double* sy, con
          if ((trip & 31) == 0) word = (unsigned)__builtin_amdgcn_readfirstlane((int)plWords[trip >> 5]);
          if (!((word >> (trip & 31)) & 1u)) continue;
       }
-      double2 X[4], Y[4], Z[4];
+      real2 X[4], Y[4], Z[4];
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
-         X[v] = *reinterpret_cast<const double2*>(sx + j + 2 * v);
-         Y[v] = *reinterpret_cast<const double2*>(sy + j + 2 * v);
-         Z[v] = *reinterpret_cast<const double2*>(sz + j + 2 * v);
+         X[v] = *reinterpret_cast<const real2*>(sx + j + 2 * v);
+         Y[v] = *reinterpret_cast<const real2*>(sy + j + 2 * v);
+         Z[v] = *reinterpret_cast<const real2*>(sz + j + 2 * v);
       }
       bool near = false;
 #pragma unroll
@@ -205,16 +205,16 @@ __device__ __forceinline__ void slabLoop(const double* sx, const double* sy, con
 #pragma unroll
          for (int u = 0; u < NA; ++u) {
             {
-               const double dx = xi[u] - X[v].x, dy = yi[u] - Y[v].x, dz = zi[u] - Z[v].x;
-               const double r2 = dx*dx + dy*dy + dz*dz;
+               const real_t dx = xi[u] - X[v].x, dy = yi[u] - Y[v].x, dz = zi[u] - Z[v].x;
+               const real_t r2 = dx*dx + dy*dy + dz*dz;
                if (PL == 1) near = near || (own[u] && r2 <= plCut2);
-               if (SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2)) ljPair<ENERGY>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
+               if (SELF ? (r2 <= a.rc2 && r2 > R(0.0)) : (r2 <= a.rc2)) ljPair<ENERGY>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
             }
             {
-               const double dx = xi[u] - X[v].y, dy = yi[u] - Y[v].y, dz = zi[u] - Z[v].y;
-               const double r2 = dx*dx + dy*dy + dz*dz;
+               const real_t dx = xi[u] - X[v].y, dy = yi[u] - Y[v].y, dz = zi[u] - Z[v].y;
+               const real_t r2 = dx*dx + dy*dy + dz*dz;
                if (PL == 1) near = near || (own[u] && r2 <= plCut2);
-               if (SELF ? (r2 <= a.rc2 && r2 > 0.0) : (r2 <= a.rc2)) ljPair<ENERGY>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
+               if (SELF ? (r2 <= a.rc2 && r2 > R(0.0)) : (r2 <= a.rc2)) ljPair<ENERGY>(dx, dy, dz, r2, a, fx[u], fy[u], fz[u], e[u]);
             }
          }
       }
@@ -232,9 +232,9 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    const int slabCap = LJ_CTA_CELLS * a.cap + 8;            // cannot overflow: a cell never holds more than cap atoms
-   double* sx = (double*)ldsRaw;
-   double* sy = sx + slabCap;
-   double* sz = sy + slabCap;
+   real_t* sx = (real_t*)ldsRaw;
+   real_t* sy = sx + slabCap;
+   real_t* sz = sy + slabCap;
    int* sOff = (int*)(sz + slabCap);                        // offsets of the slab's cells
 
    const int ci = xcdRemap(blockIdx.x, gridDim.x);
@@ -244,7 +244,7 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
    const int nThreads = blockDim.x;
 
    // each thread owns up to two atoms (cells of up to 2 * blockDim atoms): t and t + blockDim
-   double xi[2], yi[2], zi[2], fx[2] = {0.0, 0.0}, fy[2] = {0.0, 0.0}, fz[2] = {0.0, 0.0}, e[2] = {0.0, 0.0};
+   real_t xi[2], yi[2], zi[2], fx[2] = {R(0.0), R(0.0)}, fy[2] = {R(0.0), R(0.0)}, fz[2] = {R(0.0), R(0.0)}, e[2] = {R(0.0), R(0.0)};
    bool own[2];
 #pragma unroll
    for (int u = 0; u < 2; ++u) {
@@ -276,7 +276,7 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
          }
       }
       if (threadIdx.x < 8 && nSlab + threadIdx.x < ((nSlab + 7) & ~7)) {          // pad to a multiple of 8 with far-away points
-         sx[nSlab + threadIdx.x] = 1.0e30; sy[nSlab + threadIdx.x] = 1.0e30; sz[nSlab + threadIdx.x] = 1.0e30;
+         sx[nSlab + threadIdx.x] = FAR_AWAY; sy[nSlab + threadIdx.x] = FAR_AWAY; sz[nSlab + threadIdx.x] = FAR_AWAY;
       }
       __syncthreads();
 
@@ -289,12 +289,12 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
          else         slabLoop<2, PL, false, ENERGY>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);
       }
    }
-   const double fs = 24.0 * a.eps;
+   const real_t fs = R(24.0) * a.eps;
 #pragma unroll
    for (int u = 0; u < 2; ++u)
       if (own[u]) {
          const size_t io = (size_t)iBox * a.cap + threadIdx.x + u * nThreads;
          a.fx[io] = fx[u] * fs; a.fy[io] = fy[u] * fs; a.fz[io] = fz[u] * fs;
-         if (ENERGY) a.e[io] = e[u] * 2.0 * a.eps;
+         if (ENERGY) a.e[io] = e[u] * R(2.0) * a.eps;
       }
 }

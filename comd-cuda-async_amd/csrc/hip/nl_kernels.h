@@ -37,15 +37,15 @@ __device__ __forceinline__ bool nlSlot(const int* __restrict__ cells, const int*
 
 // ---- build: every atom within rBuild of atom i (27-cell stencil, self excluded), positions snapshotted into lastR ----------
 __global__ __launch_bounds__(256)
-void BuildNeighborList(const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
+void BuildNeighborList(const real_t* __restrict__ rx, const real_t* __restrict__ ry, const real_t* __restrict__ rz,
                        const int* __restrict__ nAtoms, const int* __restrict__ nbr, const int* __restrict__ cells, int nCells, int cap,
-                       NlView nl, double rBuild2, double* __restrict__ lastX, double* __restrict__ lastY, double* __restrict__ lastZ,
+                       NlView nl, real_t rBuild2, real_t* __restrict__ lastX, real_t* __restrict__ lastY, real_t* __restrict__ lastZ,
                        int* __restrict__ status)
 {
    int iBox, i;
    if (!nlSlot(cells, nAtoms, nCells, cap, iBox, i)) return;
    const size_t iSlot = (size_t)iBox * cap + i;
-   const double xi = rx[iSlot], yi = ry[iSlot], zi = rz[iSlot];
+   const real_t xi = rx[iSlot], yi = ry[iSlot], zi = rz[iSlot];
    lastX[iSlot] = xi; lastY[iSlot] = yi; lastZ[iSlot] = zi;
    int* __restrict__ row = nl.list + (size_t)iBox * nl.maxNbr * cap + i;
    int n = 0;
@@ -54,8 +54,8 @@ void BuildNeighborList(const double* __restrict__ rx, const double* __restrict__
       const int nj = nAtoms[jBox];
       const size_t base = (size_t)jBox * cap;
       for (int j = 0; j < nj; ++j) {
-         const double dx = xi - rx[base + j], dy = yi - ry[base + j], dz = zi - rz[base + j];
-         const double r2 = dx*dx + dy*dy + dz*dz;
+         const real_t dx = xi - rx[base + j], dy = yi - ry[base + j], dz = zi - rz[base + j];
+         const real_t r2 = dx*dx + dy*dy + dz*dz;
          if (r2 <= rBuild2 && base + j != iSlot) {
             if (n < nl.maxNbr) row[(size_t)n * cap] = (int)(base + j);
             ++n;
@@ -68,14 +68,14 @@ void BuildNeighborList(const double* __restrict__ rx, const double* __restrict__
 
 // gpu_kernels.cu:1087-1110: has any local atom moved more than skin/2 since the build?
 __global__ __launch_bounds__(256)
-void NeighborListUpdateRequired(const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
-                                const double* __restrict__ lastX, const double* __restrict__ lastY, const double* __restrict__ lastZ,
-                                const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double skinHalf2, int* __restrict__ flag)
+void NeighborListUpdateRequired(const real_t* __restrict__ rx, const real_t* __restrict__ ry, const real_t* __restrict__ rz,
+                                const real_t* __restrict__ lastX, const real_t* __restrict__ lastY, const real_t* __restrict__ lastZ,
+                                const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t skinHalf2, int* __restrict__ flag)
 {
    int iBox, i;
    if (!nlSlot(nullptr, nAtoms, nLocalBoxes, cap, iBox, i)) return;
    const size_t s = (size_t)iBox * cap + i;
-   const double dx = rx[s] - lastX[s], dy = ry[s] - lastY[s], dz = rz[s] - lastZ[s];
+   const real_t dx = rx[s] - lastX[s], dy = ry[s] - lastY[s], dz = rz[s] - lastZ[s];
    if (dx*dx + dy*dy + dz*dz > skinHalf2) *flag = 1;
 }
 
@@ -87,32 +87,32 @@ void LJ_Force_thread_atom_nl(LjArgs a, NlView nl)
    int iBox, i;
    if (!nlSlot(a.cells, a.nAtoms, a.nCells, a.cap, iBox, i)) return;
    const size_t iSlot = (size_t)iBox * a.cap + i;
-   const double xi = a.rx[iSlot], yi = a.ry[iSlot], zi = a.rz[iSlot];
+   const real_t xi = a.rx[iSlot], yi = a.ry[iSlot], zi = a.rz[iSlot];
    const int n = nl.count[iSlot];
    const int* __restrict__ row = nl.list + (size_t)iBox * nl.maxNbr * a.cap + i;
-   double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+   real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0);
    int k = 0;
    for (; k + 4 <= n; k += 4) {                 // four gathers in flight
-      int j[4]; double dx[4], dy[4], dz[4];
+      int j[4]; real_t dx[4], dy[4], dz[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) j[u] = row[(size_t)(k + u) * a.cap];
 #pragma unroll
       for (int u = 0; u < 4; ++u) { dx[u] = xi - a.rx[j[u]]; dy[u] = yi - a.ry[j[u]]; dz[u] = zi - a.rz[j[u]]; }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-         const double r2 = dx[u]*dx[u] + dy[u]*dy[u] + dz[u]*dz[u];
+         const real_t r2 = dx[u]*dx[u] + dy[u]*dy[u] + dz[u]*dz[u];
          if (r2 <= a.rc2) ljPair<ENERGY>(dx[u], dy[u], dz[u], r2, a, fx, fy, fz, e);
       }
    }
    for (; k < n; ++k) {
       const int j = row[(size_t)k * a.cap];
-      const double dx = xi - a.rx[j], dy = yi - a.ry[j], dz = zi - a.rz[j];
-      const double r2 = dx*dx + dy*dy + dz*dz;
+      const real_t dx = xi - a.rx[j], dy = yi - a.ry[j], dz = zi - a.rz[j];
+      const real_t r2 = dx*dx + dy*dy + dz*dz;
       if (r2 <= a.rc2) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
    }
-   const double fs = 24.0 * a.eps;
+   const real_t fs = R(24.0) * a.eps;
    a.fx[iSlot] = fx * fs; a.fy[iSlot] = fy * fs; a.fz[iSlot] = fz * fs;
-   if (ENERGY) a.e[iSlot] = e * 2.0 * a.eps;
+   if (ENERGY) a.e[iSlot] = e * R(2.0) * a.eps;
 }
 
 // ---- EAM passes 1 and 3 over the list; tables in LDS when they fit (funcfl), else through L2 (setfl) ----------------------------
@@ -121,9 +121,9 @@ __global__ __launch_bounds__(256)
 void EAM_Force_thread_atom_nl(EamArgs a, NlView nl)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
-   double* sRho = (double*)ldsRaw;
+   real_t* sRho = (real_t*)ldsRaw;
    const int nRhoPad = a.rho.n + 3, nPhiPad = (STEP == 1) ? a.phi.n + 3 : 0;
-   double* sPhi = sRho + nRhoPad;
+   real_t* sPhi = sRho + nRhoPad;
    const bool sameGrid = (STEP == 1) && LDS_TABLES && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
    if (LDS_TABLES) {
       if (sameGrid) {
@@ -139,13 +139,13 @@ void EAM_Force_thread_atom_nl(EamArgs a, NlView nl)
    int iBox, i;
    if (!nlSlot(a.cells, a.nAtoms, a.nCells, a.cap, iBox, i)) return;
    const size_t iSlot = (size_t)iBox * a.cap + i;
-   const double xi = a.rx[iSlot], yi = a.ry[iSlot], zi = a.rz[iSlot];
+   const real_t xi = a.rx[iSlot], yi = a.ry[iSlot], zi = a.rz[iSlot];
    const int n = nl.count[iSlot];
    const int* __restrict__ row = nl.list + (size_t)iBox * nl.maxNbr * a.cap + i;
-   double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0, dfi = 0.0;
+   real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0), dfi = R(0.0);
    if (STEP == 3) { fx = a.fx[iSlot]; fy = a.fy[iSlot]; fz = a.fz[iSlot]; dfi = a.dfEmbed[iSlot]; }
    for (int k0 = 0; k0 < n; k0 += 4) {
-      int j[4]; double dx[4], dy[4], dz[4], dfj[4];
+      int j[4]; real_t dx[4], dy[4], dz[4], dfj[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) j[u] = (k0 + u < n) ? row[(size_t)(k0 + u) * a.cap] : (int)iSlot;     // padding pairs have r2 = 0 and are rejected
 #pragma unroll
@@ -155,12 +155,12 @@ void EAM_Force_thread_atom_nl(EamArgs a, NlView nl)
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-         const double r2 = dx[u]*dx[u] + dy[u]*dy[u] + dz[u]*dz[u];
-         if (r2 <= a.rc2 && r2 > 0.0) {
-            const double ir = rsqrt64(r2), r = r2 * ir;
-            double rho, drho, dphi;
+         const real_t r2 = dx[u]*dx[u] + dy[u]*dy[u] + dz[u]*dz[u];
+         if (r2 <= a.rc2 && r2 > R(0.0)) {
+            const real_t ir = rsqrtR(r2), r = r2 * ir;
+            real_t rho, drho, dphi;
             if (STEP == 1) {
-               double phi;
+               real_t phi;
                if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
                else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
                e += phi; rb += rho;
@@ -174,7 +174,7 @@ void EAM_Force_thread_atom_nl(EamArgs a, NlView nl)
       }
    }
    a.fx[iSlot] = fx; a.fy[iSlot] = fy; a.fz[iSlot] = fz;
-   if (STEP == 1) { a.e[iSlot] = 0.5 * e; a.rhobar[iSlot] = rb; }
+   if (STEP == 1) { a.e[iSlot] = R(0.5) * e; a.rhobar[iSlot] = rb; }
 }
 
 // ====================================================================================================================
@@ -224,19 +224,19 @@ __device__ __forceinline__ int groupCell(int g, int kk)
 // (launched with the cell capacity), LDS = 3 * groupCapacity doubles.  Fetching the candidates with per-lane global loads instead
 // costs 22 ms per build at 80^3 (address rate of uniform loads); this form 2-3 ms.
 __global__ __launch_bounds__(512)
-void BuildNeighborListSlabs(const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
+void BuildNeighborListSlabs(const real_t* __restrict__ rx, const real_t* __restrict__ ry, const real_t* __restrict__ rz,
                             const int* __restrict__ nAtoms, const int* __restrict__ nbr, int nCells, int cap,
-                            NlSlabView nl, double rBuild2, double* __restrict__ lastX, double* __restrict__ lastY, double* __restrict__ lastZ,
+                            NlSlabView nl, real_t rBuild2, real_t* __restrict__ lastX, real_t* __restrict__ lastY, real_t* __restrict__ lastZ,
                             int* __restrict__ stats, int* __restrict__ status)
 {
-   extern __shared__ __attribute__((aligned(16))) double ldsPos[];
-   double* __restrict__ sp = ldsPos;
+   extern __shared__ __attribute__((aligned(16))) real_t ldsPos[];
+   real_t* __restrict__ sp = ldsPos;
    const int iBox = blockIdx.x;
    const int i = threadIdx.x;
    const int ni = nAtoms[iBox];
    const bool active = i < ni;
    const size_t iSlot = (size_t)iBox * cap + (active ? i : 0);
-   const double xi = rx[iSlot], yi = ry[iSlot], zi = rz[iSlot];
+   const real_t xi = rx[iSlot], yi = ry[iSlot], zi = rz[iSlot];
    if (active) { lastX[iSlot] = xi; lastY[iSlot] = yi; lastZ[iSlot] = zi; }
    if (i == 0) atomicMax(&stats[1], ni);
    bool over = false;
@@ -244,7 +244,7 @@ void BuildNeighborListSlabs(const double* __restrict__ rx, const double* __restr
       if (g) __syncthreads();
       int total = 0, selfAt = -1;                      // records of the group; where this cell's own atoms start in it (-1: not in this group)
       {
-         double vx[NL_GROUP_CELLS], vy[NL_GROUP_CELLS], vz[NL_GROUP_CELLS];
+         real_t vx[NL_GROUP_CELLS], vy[NL_GROUP_CELLS], vz[NL_GROUP_CELLS];
          int dst[NL_GROUP_CELLS];
 #pragma unroll
          for (int kk = 0; kk < NL_GROUP_CELLS; ++kk) {
@@ -268,7 +268,7 @@ void BuildNeighborListSlabs(const double* __restrict__ rx, const double* __restr
          const int me = selfAt >= 0 ? selfAt + i : -1;
          int n = 0;
          for (int t = 0; t < total; ++t) {
-            const double dx = xi - sp[3 * t], dy = yi - sp[3 * t + 1], dz = zi - sp[3 * t + 2];
+            const real_t dx = xi - sp[3 * t], dy = yi - sp[3 * t + 1], dz = zi - sp[3 * t + 2];
             if (dx*dx + dy*dy + dz*dz <= rBuild2 && t != me) {
                if (n < nl.rows) row[(size_t)n * cap] = (unsigned short)(3 * t);      // index of the x of its {x,y,z} record
                ++n;
@@ -286,20 +286,20 @@ template <bool ENERGY>
 __global__ __launch_bounds__(512)
 void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
 {
-   extern __shared__ __attribute__((aligned(16))) double ldsPos[];      // {x, y, z} records: one address per neighbour, ds_read offsets 0/8/16
-   double* __restrict__ sp = ldsPos;
+   extern __shared__ __attribute__((aligned(16))) real_t ldsPos[];      // {x, y, z} records: one address per neighbour, ds_read offsets 0/8/16
+   real_t* __restrict__ sp = ldsPos;
    (void)groupAtoms;
    const int iBox = a.cells ? a.cells[blockIdx.x] : blockIdx.x;
    const int i = threadIdx.x;
    const int ni = a.nAtoms[iBox];
    const bool active = i < ni;
    const size_t iSlot = (size_t)iBox * a.cap + (active ? i : 0);
-   const double xi = a.rx[iSlot], yi = a.ry[iSlot], zi = a.rz[iSlot];
-   double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+   const real_t xi = a.rx[iSlot], yi = a.ry[iSlot], zi = a.rz[iSlot];
+   real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0);
    for (int g = 0; g < NL_GROUPS; ++g) {
       if (g) __syncthreads();                         // everyone is done reading the previous group
       {  // all cells' loads in flight together, then the LDS stores (one global round trip per group)
-         double vx[NL_GROUP_CELLS], vy[NL_GROUP_CELLS], vz[NL_GROUP_CELLS];
+         real_t vx[NL_GROUP_CELLS], vy[NL_GROUP_CELLS], vz[NL_GROUP_CELLS];
          int dst[NL_GROUP_CELLS];
          int off = 0;
 #pragma unroll
@@ -335,27 +335,27 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
 #pragma unroll
                for (int u = 0; u < NL_BATCH; ++u) jn[u] = row[(size_t)(k + NL_BATCH + u) * a.cap];
             }
-            double dx[NL_BATCH], dy[NL_BATCH], dz[NL_BATCH];
+            real_t dx[NL_BATCH], dy[NL_BATCH], dz[NL_BATCH];
 #pragma unroll
             for (int u = 0; u < NL_BATCH; ++u) { dx[u] = xi - sp[j[u]]; dy[u] = yi - sp[j[u] + 1]; dz[u] = zi - sp[j[u] + 2]; }
 #pragma unroll
             for (int u = 0; u < NL_BATCH; ++u) {
-               const double r2 = dx[u]*dx[u] + dy[u]*dy[u] + dz[u]*dz[u];
+               const real_t r2 = dx[u]*dx[u] + dy[u]*dy[u] + dz[u]*dz[u];
                if (r2 <= a.rc2) ljPair<ENERGY>(dx[u], dy[u], dz[u], r2, a, fx, fy, fz, e);      // (evaluating all 8 branch-free, misses weighted 0: 2.09 vs 2.07 ms)
             }
          }
          for (; k < n; ++k) {
             const int j = row[(size_t)k * a.cap];
-            const double dx = xi - sp[j], dy = yi - sp[j + 1], dz = zi - sp[j + 2];
-            const double r2 = dx*dx + dy*dy + dz*dz;
+            const real_t dx = xi - sp[j], dy = yi - sp[j + 1], dz = zi - sp[j + 2];
+            const real_t r2 = dx*dx + dy*dy + dz*dz;
             if (r2 <= a.rc2) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
          }
       }
    }
    if (active) {
-      const double fs = 24.0 * a.eps;
+      const real_t fs = R(24.0) * a.eps;
       a.fx[iSlot] = fx * fs; a.fy[iSlot] = fy * fs; a.fz[iSlot] = fz * fs;
-      if (ENERGY) a.e[iSlot] = e * 2.0 * a.eps;
+      if (ENERGY) a.e[iSlot] = e * R(2.0) * a.eps;
    }
 }
 
@@ -370,16 +370,21 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
 // Build, same shape as the force kernel below: one wave per cell stages the stencil in its LDS slice; the four lanes of atom i test
 // four staged records per trip and a ballot packs their hits into consecutive rows (record order), so the rows q, q+4, ... each
 // lane reads back in the force kernel are an even quarter of the list.
+__host__ __device__ static inline size_t eamBuildWaveBytes(int stencilCapacity, int rows)
+{
+   return ((size_t)3 * stencilCapacity * sizeof(real_t) + 256 + (size_t)16 * rows * 2 + 15) & ~(size_t)15;
+}
+
 __global__ __launch_bounds__(64 * EAM_NL_WAVES)
-void BuildNeighborListCell16(const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
+void BuildNeighborListCell16(const real_t* __restrict__ rx, const real_t* __restrict__ ry, const real_t* __restrict__ rz,
                              const int* __restrict__ nAtoms, const int* __restrict__ nbr, int nCells, int cap,
-                             NlSlabView nl, double rBuild2, double* __restrict__ lastX, double* __restrict__ lastY, double* __restrict__ lastZ,
+                             NlSlabView nl, real_t rBuild2, real_t* __restrict__ lastX, real_t* __restrict__ lastY, real_t* __restrict__ lastZ,
                              int* __restrict__ stats, int* __restrict__ status, int stencilCapacity)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-   const int hitDoubles = (16 * nl.rows * 2 + 7) / 8;        // [16 atoms][rows] 16-bit entries
-   double* __restrict__ sp = (double*)ldsRaw + (size_t)wave * (3 * stencilCapacity + 32 + hitDoubles);
+   // per wave: [3 * stencilCapacity] records, [32] offsets, [32] cells, [16 atoms][rows] 16-bit entries
+   real_t* __restrict__ sp = (real_t*)(ldsRaw + (size_t)wave * eamBuildWaveBytes(stencilCapacity, nl.rows));
    int* sOff = (int*)(sp + 3 * stencilCapacity);
    int* sBox = sOff + 32;
    unsigned short* sHit = (unsigned short*)(sBox + 32);
@@ -403,7 +408,7 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
       maxTotal = total > maxTotal ? total : maxTotal; maxNi = ni > maxNi ? ni : maxNi;      // one atomic per wave at the end, not per cell
       if (total > stencilCapacity) { tooSmall = true; continue; }      // the host sees stats[0] > capacity and repeats the build (worst-case capacity: flagged)
       for (int t0 = 0; t0 < total; t0 += 256) {
-         double vx[4], vy[4], vz[4];
+         real_t vx[4], vy[4], vz[4];
 #pragma unroll
          for (int g = 0; g < 4; ++g) {
             const int t = t0 + g * 64 + lane;
@@ -426,7 +431,7 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
          const bool have = i < ni;
          const int ii = have ? i : 0;
          const size_t iSlot = (size_t)iBox * cap + ii;
-         const double xi = sp[3 * ii], yi = sp[3 * ii + 1], zi = sp[3 * ii + 2];
+         const real_t xi = sp[3 * ii], yi = sp[3 * ii + 1], zi = sp[3 * ii + 2];
          if (have && q == 0) { lastX[iSlot] = xi; lastY[iSlot] = yi; lastZ[iSlot] = zi; }
          unsigned short* __restrict__ row = nl.list + ((size_t)iBox * nl.rows) * cap + ii;
          int n = 0;                                          // hits of atom i so far (the same in its four lanes)
@@ -436,7 +441,7 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
             for (int u = 0; u < 4; ++u) {                     // the four distance tests are independent: 12 LDS reads in flight
                const int t = t0 + 4 * u + q;
                const int tt = t < total ? t : 0;
-               const double dx = xi - sp[3 * tt], dy = yi - sp[3 * tt + 1], dz = zi - sp[3 * tt + 2];
+               const real_t dx = xi - sp[3 * tt], dy = yi - sp[3 * tt + 1], dz = zi - sp[3 * tt + 2];
                hit[u] = have && t < total && dx*dx + dy*dy + dz*dz <= rBuild2 && t != i;
             }
 #pragma unroll
@@ -468,11 +473,18 @@ void BuildNeighborListCell16(const double* __restrict__ rx, const double* __rest
 }
 
 // quad sum: every lane of an aligned group of 4 ends with the group's total
-__device__ __forceinline__ double quadSum(double v)
+__device__ __forceinline__ real_t quadSum(real_t v)
 {
-   v += dppMove64<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
-   v += dppMove64<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
+   v += dppMoveR<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]
+   v += dppMoveR<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]
    return v;
+}
+
+// LDS layouts in bytes (records in the build's precision; offsets, cell ids and 16-bit rows in their own units), every part a multiple of 16
+__host__ __device__ static inline size_t eamTableBytesAligned(size_t tableWords) { return (tableWords * sizeof(real_t) + 15) & ~(size_t)15; }
+__host__ __device__ static inline size_t eamNlWaveBytes(int rec, int stencilAtoms)
+{
+   return ((size_t)rec * stencilAtoms * sizeof(real_t) + 256 + 16 * 64 * 2 + 15) & ~(size_t)15;      // records, [32] offsets + [32] cells, [16][64] row stash
 }
 
 template <int STEP>
@@ -483,8 +495,8 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
    constexpr int REC = (STEP == 3) ? 4 : 3;                  // doubles per staged atom: x, y, z [, F']
    const int nRhoPad = a.rho.n + 3;
    const bool sameGrid = (STEP == 1) && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
-   double* sRho = (double*)ldsRaw;                           // pass 1 on one r grid: interleaved {phi, rho}; else rho then phi
-   double* sPhi = sRho + nRhoPad;
+   real_t* sRho = (real_t*)ldsRaw;                           // pass 1 on one r grid: interleaved {phi, rho}; else rho then phi
+   real_t* sPhi = sRho + nRhoPad;
    const int tableDoubles = (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;
    if (sameGrid) {
       for (int t = threadIdx.x; t < nRhoPad; t += blockDim.x) { sRho[2 * t] = a.phi.values[t]; sRho[2 * t + 1] = a.rho.values[t]; }
@@ -496,7 +508,7 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
    const TableView rhoT = makeTable(a.rho, sRho), phiT = makeTable(a.phi, sPhi);
 
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-   double* __restrict__ sp = (double*)ldsRaw + ((tableDoubles + 1) & ~1) + (size_t)wave * (REC * stencilAtoms + 32 + 256);
+   real_t* __restrict__ sp = (real_t*)(ldsRaw + eamTableBytesAligned(tableDoubles) + (size_t)wave * eamNlWaveBytes(REC, stencilAtoms));
    int* sOff = (int*)(sp + REC * stencilAtoms);              // [32]: exclusive record offsets of the 27 cells, [27] = total
    int* sBox = sOff + 32;                                    // [32]
    unsigned short* sEnt = (unsigned short*)(sBox + 32);      // [16][64]: the rows a lane fetched for the current round
@@ -520,7 +532,7 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
    if (ciBegin < ciEnd)     { const int c = cellOf(ciBegin);     boxA = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntA = lane < 27 ? a.nAtoms[boxA] : 0; }
    if (ciBegin + 1 < ciEnd) { const int c = cellOf(ciBegin + 1); boxB = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntB = lane < 27 ? a.nAtoms[boxB] : 0; }
 
-   double vx[SR], vy[SR], vz[SR], vd[SR];
+   real_t vx[SR], vy[SR], vz[SR], vd[SR];
    int ent[CH];
    int nMine = 0, totalL = 0, niL = 0, iBoxL = 0;            // of the cell whose loads are in flight
 
@@ -563,7 +575,7 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
       for (int g = 0; g < SR; ++g) {
          const int t = g * 64 + lane;
          if (t < total) {
-            double* r = sp + REC * t;
+            real_t* r = sp + REC * t;
             r[0] = vx[g]; r[1] = vy[g]; r[2] = vz[g];
             if (STEP == 3) r[3] = vd[g];
          }
@@ -573,7 +585,7 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
 #pragma unroll
          for (int step = 16; step >= 1; step >>= 1) { const int m = lo + step; if (m <= 26 && sOff[m] <= t) lo = m; }
          const size_t o = (size_t)sBox[lo] * a.cap + (t - sOff[lo]);
-         double* r = sp + REC * t;
+         real_t* r = sp + REC * t;
          r[0] = a.rx[o]; r[1] = a.ry[o]; r[2] = a.rz[o];
          if (STEP == 3) r[3] = a.dfEmbed[o];
       }
@@ -602,18 +614,18 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
          const int i = i0 + ia;
          const bool have = i < ni;
          const int ii = have ? i : 0;
-         const double xi = sp[REC * ii], yi = sp[REC * ii + 1], zi = sp[REC * ii + 2];      // own cell is staged first: record i
-         const double dfi = (STEP == 3) ? sp[REC * ii + 3] : 0.0;
-         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0;
+         const real_t xi = sp[REC * ii], yi = sp[REC * ii + 1], zi = sp[REC * ii + 2];      // own cell is staged first: record i
+         const real_t dfi = (STEP == 3) ? sp[REC * ii + 3] : R(0.0);
+         real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0);
          auto pairEval = [&](int j) {
-            const double* r0 = sp + REC * j;
-            const double dx = xi - r0[0], dy = yi - r0[1], dz = zi - r0[2];
-            const double r2 = dx*dx + dy*dy + dz*dz;
-            if (r2 <= a.rc2 && r2 > 0.0) {
-               const double ir = rsqrt64(r2), r = r2 * ir;
-               double rho, drho, dphi;
+            const real_t* r0 = sp + REC * j;
+            const real_t dx = xi - r0[0], dy = yi - r0[1], dz = zi - r0[2];
+            const real_t r2 = dx*dx + dy*dy + dz*dz;
+            if (r2 <= a.rc2 && r2 > R(0.0)) {
+               const real_t ir = rsqrtR(r2), r = r2 * ir;
+               real_t rho, drho, dphi;
                if (STEP == 1) {
-                  double phi;
+                  real_t phi;
                   if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
                   else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
                   e += phi; rb += rho;
@@ -628,26 +640,26 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
          // two pairs per trip, branch-free (a miss is evaluated at r = cutoff and weighted 0): two independent chains of LDS table
          // reads and fp64 arithmetic in flight per lane -- with 2 waves per SIMD the chains hide each other's latency
          auto pairEval2 = [&](int j0, int j1, bool two) {
-            const double* r0 = sp + REC * j0; const double* r1 = sp + REC * j1;
-            const double dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
-            const double dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
-            const double q0 = dx0*dx0 + dy0*dy0 + dz0*dz0, q1 = dx1*dx1 + dy1*dy1 + dz1*dz1;
-            const bool h0 = q0 <= a.rc2 && q0 > 0.0, h1 = two && q1 <= a.rc2 && q1 > 0.0;
-            const double s0 = h0 ? q0 : a.rc2, s1 = h1 ? q1 : a.rc2;
-            const double ir0 = rsqrt64(s0), ir1 = rsqrt64(s1);
-            const double d0 = s0 * ir0, d1 = s1 * ir1;
-            double rho0, drho0, dphi0, rho1, drho1, dphi1;
+            const real_t* r0 = sp + REC * j0; const real_t* r1 = sp + REC * j1;
+            const real_t dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
+            const real_t dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
+            const real_t q0 = dx0*dx0 + dy0*dy0 + dz0*dz0, q1 = dx1*dx1 + dy1*dy1 + dz1*dz1;
+            const bool h0 = q0 <= a.rc2 && q0 > R(0.0), h1 = two && q1 <= a.rc2 && q1 > R(0.0);
+            const real_t s0 = h0 ? q0 : a.rc2, s1 = h1 ? q1 : a.rc2;
+            const real_t ir0 = rsqrtR(s0), ir1 = rsqrtR(s1);
+            const real_t d0 = s0 * ir0, d1 = s1 * ir1;
+            real_t rho0, drho0, dphi0, rho1, drho1, dphi1;
             if (STEP == 1) {
-               double phi0, phi1;
+               real_t phi0, phi1;
                if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
                else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
-               e += (h0 ? phi0 : 0.0) + (h1 ? phi1 : 0.0);
-               rb += (h0 ? rho0 : 0.0) + (h1 ? rho1 : 0.0);
+               e += (h0 ? phi0 : R(0.0)) + (h1 ? phi1 : R(0.0));
+               rb += (h0 ? rho0 : R(0.0)) + (h1 ? rho1 : R(0.0));
             } else {
                interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
                dphi0 = (dfi + r0[3 % REC]) * drho0; dphi1 = (dfi + r1[3 % REC]) * drho1;
             }
-            dphi0 = h0 ? dphi0 * ir0 : 0.0; dphi1 = h1 ? dphi1 * ir1 : 0.0;
+            dphi0 = h0 ? dphi0 * ir0 : R(0.0); dphi1 = h1 ? dphi1 * ir1 : R(0.0);
             fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
             fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
          };
@@ -662,7 +674,7 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
          if (STEP == 1) { e = quadSum(e); rb = quadSum(rb); }
          if (have && q == 0) {
             const size_t io = (size_t)iBox * a.cap + i;
-            if (STEP == 1) { a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = 0.5 * e; a.rhobar[io] = rb; }
+            if (STEP == 1) { a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = R(0.5) * e; a.rhobar[io] = rb; }
             else           { a.fx[io] += fx; a.fy[io] += fy; a.fz[io] += fz; }
          }
       }
@@ -673,11 +685,9 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
 static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, int stencilAtoms)
 {
    const int rec = step == 3 ? 4 : 3;
-   size_t tableDoubles = step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
-   tableDoubles = (tableDoubles + 1) & ~(size_t)1;
-   return (tableDoubles + (size_t)EAM_NL_WAVES * ((size_t)rec * stencilAtoms + 32 + 256)) * sizeof(double);      // + offsets/cells + row stash
+   const size_t tableWords = step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
+   return eamTableBytesAligned(tableWords) + (size_t)EAM_NL_WAVES * eamNlWaveBytes(rec, stencilAtoms);
 }
-
 
 // ====================================================================================================================
 // EAM_Force_cta_cell (method cta_cell, no Verlet lists): the list kernel above with the list built on the fly.
@@ -693,6 +703,12 @@ static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, 
 //   pipe  : while cell c is built and evaluated out of the LDS, the records of c+1 are in flight into registers and the
 //           description of c+2 (two dependent reads) is on its way.
 // No cross-lane traffic beyond the quad, no queue shared by 64 lanes, and per lane long runs of independent work.
+__host__ __device__ static inline size_t eamCtaWaveBytes(int rec, int stencilAtoms, int rows)
+{
+   // records (+ F' in pass 3), [32] offsets + [32] cells, [16 atoms][rows] 16-bit record numbers, [16] row lengths
+   return ((size_t)rec * stencilAtoms * sizeof(real_t) + 256 + (size_t)16 * rows * 2 + 64 + 15) & ~(size_t)15;
+}
+
 template <int STEP, bool LDS_TABLES, bool SPLINE>
 __global__ __launch_bounds__(512)
 void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* __restrict__ rowsG, unsigned short* __restrict__ rowCountG,
@@ -704,8 +720,8 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
    const int nRhoPad = a.rho.n + 3;
    const int wavesPerBlock = blockDim.x >> 6;
    const bool sameGrid = (STEP == 1) && LDS_TABLES && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
-   double* sRho = (double*)ldsRaw;
-   double* sPhi = sRho + nRhoPad;
+   real_t* sRho = (real_t*)ldsRaw;
+   real_t* sPhi = sRho + nRhoPad;
    int tableDoubles = 0;
    if (LDS_TABLES) {
       tableDoubles = (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;
@@ -720,9 +736,8 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
    const TableView rhoT = makeTable(a.rho, LDS_TABLES ? sRho : a.rho.values), phiT = makeTable(a.phi, LDS_TABLES ? sPhi : a.phi.values);
 
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-   const int hitDoubles = (16 * rows * 2 + 7) / 8 + 8;       // [16 atoms][rows] 16-bit record numbers + [16] row lengths
-   double* __restrict__ sp = (double*)ldsRaw + ((tableDoubles + 1) & ~1) + (size_t)wave * ((REC + RECD) * stencilAtoms + 32 + hitDoubles);
-   double* __restrict__ sd = sp + REC * stencilAtoms;        // [stencilAtoms] F' (pass 3)
+   real_t* __restrict__ sp = (real_t*)(ldsRaw + eamTableBytesAligned(tableDoubles) + (size_t)wave * eamCtaWaveBytes(REC + RECD, stencilAtoms, rows));
+   real_t* __restrict__ sd = sp + REC * stencilAtoms;        // [stencilAtoms] F' (pass 3)
    int* sOff = (int*)(sp + (REC + RECD) * stencilAtoms);     // [32]: exclusive record offsets of the 27 cells, [27] = total
    int* sBox = sOff + 32;                                    // [32]
    unsigned short* sHit = (unsigned short*)(sBox + 32);
@@ -741,7 +756,7 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
    if (ciBegin < ciEnd)     { const int c = cellOf(ciBegin);     boxA = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntA = lane < 27 ? a.nAtoms[boxA] : 0; }
    if (ciBegin + 1 < ciEnd) { const int c = cellOf(ciBegin + 1); boxB = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntB = lane < 27 ? a.nAtoms[boxB] : 0; }
 
-   double vx[SR], vy[SR], vz[SR], vd[SR];
+   real_t vx[SR], vy[SR], vz[SR], vd[SR];
    constexpr int RJ = 4;                                     // 16-byte row chunks a lane keeps in flight (pass 3): 16 rows of up to 128 entries
    uint4 rowReg[RJ];
    int rowCnt = 0;
@@ -800,7 +815,7 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
          for (int g = 0; g < SR; ++g) {
             const int t = g * 64 + lane;
             if (t < total) {
-               double* r = sp + REC * t;
+               real_t* r = sp + REC * t;
                r[0] = vx[g]; r[1] = vy[g]; r[2] = vz[g];
                if (STEP == 3) sd[t] = vd[g];
             }
@@ -810,7 +825,7 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
 #pragma unroll
             for (int step = 16; step >= 1; step >>= 1) { const int m = lo + step; if (m <= 26 && sOff[m] <= t) lo = m; }
             const size_t o = (size_t)sBox[lo] * a.cap + (t - sOff[lo]);
-            double* r = sp + REC * t;
+            real_t* r = sp + REC * t;
             r[0] = a.rx[o]; r[1] = a.ry[o]; r[2] = a.rz[o];
             if (STEP == 3) sd[t] = a.dfEmbed[o];
          }
@@ -840,11 +855,11 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
          const int i = i0 + ia;
          const bool have = ia < nRound;
          const int ii = have ? i : 0;
-         const double xi = sp[REC * ii], yi = sp[REC * ii + 1], zi = sp[REC * ii + 2];      // own cell is staged first: record i
-         const double dfi = (STEP == 3) ? sd[ii] : 0.0;
+         const real_t xi = sp[REC * ii], yi = sp[REC * ii + 1], zi = sp[REC * ii + 2];      // own cell is staged first: record i
+         const real_t dfi = (STEP == 3) ? sd[ii] : R(0.0);
          // pass 3 adds to the forces of pass 1: ask for them now, a whole round of arithmetic before they are needed
          const size_t io = (size_t)iBox * a.cap + ii;
-         double f0x = 0.0, f0y = 0.0, f0z = 0.0;
+         real_t f0x = R(0.0), f0y = R(0.0), f0z = R(0.0);
          if (STEP == 3 && have && q == 0) { f0x = a.fx[io]; f0y = a.fy[io]; f0z = a.fz[io]; }
          unsigned short* __restrict__ myRow = sHit + (have ? ia : 0) * rows;
          if (STEP == 3) {
@@ -864,18 +879,18 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
             // tests); ballot + mbcnt append the hits, in record order, to the two atoms' rows
             for (int pa = 0; pa < nRound; pa += 2) {
                const int iA = i0 + pa, iB = pa + 1 < nRound ? iA + 1 : iA;
-               const double xA = sp[REC * iA], yA = sp[REC * iA + 1], zA = sp[REC * iA + 2];
-               const double xB = sp[REC * iB], yB = sp[REC * iB + 1], zB = sp[REC * iB + 2];
+               const real_t xA = sp[REC * iA], yA = sp[REC * iA + 1], zA = sp[REC * iA + 2];
+               const real_t xB = sp[REC * iB], yB = sp[REC * iB + 1], zB = sp[REC * iB + 2];
                unsigned short* __restrict__ rowA = sHit + pa * rows;
                unsigned short* __restrict__ rowB = rowA + rows;
                int nA = 0, nB = 0;
                for (int t0 = 0; t0 < total; t0 += 64) {
                   const int t = t0 + lane;
                   const int tt = t < total ? t : 0;
-                  const double px = sp[REC * tt], py = sp[REC * tt + 1], pz = sp[REC * tt + 2];
-                  const double ax = xA - px, ay = yA - py, az = zA - pz;
-                  const double bx = xB - px, by = yB - py, bz = zB - pz;
-                  const double r2A = ax * ax + ay * ay + az * az, r2B = bx * bx + by * by + bz * bz;
+                  const real_t px = sp[REC * tt], py = sp[REC * tt + 1], pz = sp[REC * tt + 2];
+                  const real_t ax = xA - px, ay = yA - py, az = zA - pz;
+                  const real_t bx = xB - px, by = yB - py, bz = zB - pz;
+                  const real_t r2A = ax * ax + ay * ay + az * az, r2B = bx * bx + by * by + bz * bz;
                   // records 0 .. ni-1 are the cell itself: only they can be the atom (r2 = 0); lanes past the list re-read record 0
                   const bool live = t < total;
                   const bool hitA = live && r2A <= a.rc2 && t != iA;
@@ -902,42 +917,42 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
             if (lane < nRound) rowCountG[(size_t)iBox * a.cap + i0 + lane] = (unsigned short)(sCnt[lane] < rows ? sCnt[lane] : rows);
          }
 
-         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0;
+         real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0);
          // two pairs per trip, branch-free (a missing second pair is evaluated at r = cutoff and weighted 0)
          for (int k0 = q; k0 < n; k0 += 2 * L) {             // this lane's rows: q, q + L, q + 2L, ... < n
             const bool h1 = k0 + L < n;
             const int j0 = myRow[k0], j1 = h1 ? myRow[k0 + L] : ii;
-            const double* r0 = sp + REC * j0; const double* r1 = sp + REC * j1;
-            const double dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
-            const double dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
-            const double s0 = dx0*dx0 + dy0*dy0 + dz0*dz0;
-            const double s1 = h1 ? dx1*dx1 + dy1*dy1 + dz1*dz1 : a.rc2;
-            double rho0, drho0, dphi0, rho1, drho1, dphi1;
+            const real_t* r0 = sp + REC * j0; const real_t* r1 = sp + REC * j1;
+            const real_t dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
+            const real_t dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
+            const real_t s0 = dx0*dx0 + dy0*dy0 + dz0*dz0;
+            const real_t s1 = h1 ? dx1*dx1 + dy1*dy1 + dz1*dz1 : a.rc2;
+            real_t rho0, drho0, dphi0, rho1, drho1, dphi1;
             if (SPLINE) {                                    // -P: cubic splines in r^2 give (1/r) d/dr directly, no square root
                interpolateSpline(a.rhoS, s0, rho0, drho0); interpolateSpline(a.rhoS, s1, rho1, drho1);
                if (STEP == 1) {
-                  double phi0, phi1;
+                  real_t phi0, phi1;
                   interpolateSpline(a.phiS, s0, phi0, dphi0); interpolateSpline(a.phiS, s1, phi1, dphi1);
-                  e += phi0 + (h1 ? phi1 : 0.0);
-                  rb += rho0 + (h1 ? rho1 : 0.0);
+                  e += phi0 + (h1 ? phi1 : R(0.0));
+                  rb += rho0 + (h1 ? rho1 : R(0.0));
                } else {
                   dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
                }
-               dphi1 = h1 ? dphi1 : 0.0;
+               dphi1 = h1 ? dphi1 : R(0.0);
             } else {
-               const double ir0 = rsqrt64(s0), ir1 = rsqrt64(s1);
-               const double d0 = s0 * ir0, d1 = s1 * ir1;
+               const real_t ir0 = rsqrtR(s0), ir1 = rsqrtR(s1);
+               const real_t d0 = s0 * ir0, d1 = s1 * ir1;
                if (STEP == 1) {
-                  double phi0, phi1;
+                  real_t phi0, phi1;
                   if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
                   else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
-                  e += phi0 + (h1 ? phi1 : 0.0);
-                  rb += rho0 + (h1 ? rho1 : 0.0);
+                  e += phi0 + (h1 ? phi1 : R(0.0));
+                  rb += rho0 + (h1 ? rho1 : R(0.0));
                } else {
                   interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
                   dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
                }
-               dphi0 = dphi0 * ir0; dphi1 = h1 ? dphi1 * ir1 : 0.0;
+               dphi0 = dphi0 * ir0; dphi1 = h1 ? dphi1 * ir1 : R(0.0);
             }
             fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
             fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
@@ -950,13 +965,13 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) {
                const bool take = q + d < L;
-               const double tx = __shfl_down(fx, d), ty = __shfl_down(fy, d), tz = __shfl_down(fz, d);
-               fx += take ? tx : 0.0; fy += take ? ty : 0.0; fz += take ? tz : 0.0;
-               if (STEP == 1) { const double te = __shfl_down(e, d), tr = __shfl_down(rb, d); e += take ? te : 0.0; rb += take ? tr : 0.0; }
+               const real_t tx = __shfl_down(fx, d), ty = __shfl_down(fy, d), tz = __shfl_down(fz, d);
+               fx += take ? tx : R(0.0); fy += take ? ty : R(0.0); fz += take ? tz : R(0.0);
+               if (STEP == 1) { const real_t te = __shfl_down(e, d), tr = __shfl_down(rb, d); e += take ? te : R(0.0); rb += take ? tr : R(0.0); }
             }
          }
          if (have && q == 0) {
-            if (STEP == 1) { a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = 0.5 * e; a.rhobar[io] = rb; }
+            if (STEP == 1) { a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = R(0.5) * e; a.rhobar[io] = rb; }
             else           { a.fx[io] = f0x + fx; a.fy[io] = f0y + fy; a.fz[io] = f0z + fz; }
          }
          __builtin_amdgcn_wave_barrier();
@@ -968,8 +983,7 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
 static inline size_t eamCtaCellLdsBytes(int step, int nRho, int nPhi, bool ldsTables, bool sameGrid, int stencilAtoms, int rows, int wavesPerBlock)
 {
    const int rec = step == 3 ? 4 : 3;
-   size_t tableDoubles = 0;
-   if (ldsTables) tableDoubles = step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
-   tableDoubles = (tableDoubles + 1) & ~(size_t)1;
-   return (tableDoubles + (size_t)wavesPerBlock * ((size_t)rec * stencilAtoms + 32 + (16 * (size_t)rows * 2 + 7) / 8 + 8)) * sizeof(double);
+   size_t tableWords = 0;
+   if (ldsTables) tableWords = step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
+   return eamTableBytesAligned(tableWords) + (size_t)wavesPerBlock * eamCtaWaveBytes(rec, stencilAtoms, rows);
 }

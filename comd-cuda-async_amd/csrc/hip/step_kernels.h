@@ -14,9 +14,9 @@
 
 // ---- integrator -------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256)
-void AdvanceVelocity(double* __restrict__ px, double* __restrict__ py, double* __restrict__ pz,
-                     const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
-                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double dt)
+void AdvanceVelocity(real_t* __restrict__ px, real_t* __restrict__ py, real_t* __restrict__ pz,
+                     const real_t* __restrict__ fx, const real_t* __restrict__ fy, const real_t* __restrict__ fz,
+                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dt)
 {
    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(tid / cap);
@@ -25,31 +25,31 @@ void AdvanceVelocity(double* __restrict__ px, double* __restrict__ py, double* _
 }
 
 __global__ __launch_bounds__(256)
-void AdvancePosition(double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
-                     const double* __restrict__ px, const double* __restrict__ py, const double* __restrict__ pz,
-                     const int* __restrict__ iSpecies, const double* __restrict__ speciesMass,
-                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double dt)
+void AdvancePosition(real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* __restrict__ rz,
+                     const real_t* __restrict__ px, const real_t* __restrict__ py, const real_t* __restrict__ pz,
+                     const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
+                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dt)
 {
    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(tid / cap);
    if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
-   const double invMass = 1.0 / speciesMass[iSpecies[tid]];  // same expression order as timestep.c:168-173
+   const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];  // same expression order as timestep.c:168-173
    rx[tid] += dt * px[tid] * invMass; ry[tid] += dt * py[tid] * invMass; rz[tid] += dt * pz[tid] * invMass;
 }
 
 // half kick followed by the drift in one pass (same operations, same order, as AdvanceVelocity then AdvancePosition)
 __global__ __launch_bounds__(256)
-void AdvanceVelocityPosition(double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
-                             double* __restrict__ px, double* __restrict__ py, double* __restrict__ pz,
-                             const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
-                             const int* __restrict__ iSpecies, const double* __restrict__ speciesMass,
-                             const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double dtKick, double dtDrift)
+void AdvanceVelocityPosition(real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* __restrict__ rz,
+                             real_t* __restrict__ px, real_t* __restrict__ py, real_t* __restrict__ pz,
+                             const real_t* __restrict__ fx, const real_t* __restrict__ fy, const real_t* __restrict__ fz,
+                             const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
+                             const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick, real_t dtDrift)
 {
    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(tid / cap);
    if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
-   const double invMass = 1.0 / speciesMass[iSpecies[tid]];
-   const double x = px[tid] + dtKick * fx[tid], y = py[tid] + dtKick * fy[tid], z = pz[tid] + dtKick * fz[tid];
+   const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];
+   const real_t x = px[tid] + dtKick * fx[tid], y = py[tid] + dtKick * fy[tid], z = pz[tid] + dtKick * fz[tid];
    px[tid] = x; py[tid] = y; pz[tid] = z;
    rx[tid] += dtDrift * x * invMass; ry[tid] += dtDrift * y * invMass; rz[tid] += dtDrift * z * invMass;
 }
@@ -57,18 +57,18 @@ void AdvanceVelocityPosition(double* __restrict__ rx, double* __restrict__ ry, d
 // second half kick of one step + first half kick and drift of the next, one pass (same operations, same order, as AdvanceVelocity followed
 // by AdvanceVelocityPosition: the two kicks stay two roundings)
 __global__ __launch_bounds__(256)
-void AdvanceVelocityVelocityPosition(double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
-                                     double* __restrict__ px, double* __restrict__ py, double* __restrict__ pz,
-                                     const double* __restrict__ fx, const double* __restrict__ fy, const double* __restrict__ fz,
-                                     const int* __restrict__ iSpecies, const double* __restrict__ speciesMass,
-                                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, double dtKick1, double dtKick2, double dtDrift)
+void AdvanceVelocityVelocityPosition(real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* __restrict__ rz,
+                                     real_t* __restrict__ px, real_t* __restrict__ py, real_t* __restrict__ pz,
+                                     const real_t* __restrict__ fx, const real_t* __restrict__ fy, const real_t* __restrict__ fz,
+                                     const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
+                                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick1, real_t dtKick2, real_t dtDrift)
 {
    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(tid / cap);
    if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
-   const double invMass = 1.0 / speciesMass[iSpecies[tid]];
-   const double gx = fx[tid], gy = fy[tid], gz = fz[tid];
-   double x = px[tid] + dtKick1 * gx, y = py[tid] + dtKick1 * gy, z = pz[tid] + dtKick1 * gz;
+   const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];
+   const real_t gx = fx[tid], gy = fy[tid], gz = fz[tid];
+   real_t x = px[tid] + dtKick1 * gx, y = py[tid] + dtKick1 * gy, z = pz[tid] + dtKick1 * gz;
    x += dtKick2 * gx; y += dtKick2 * gy; z += dtKick2 * gz;
    px[tid] = x; py[tid] = y; pz[tid] = z;
    rx[tid] += dtDrift * x * invMass; ry[tid] += dtDrift * y * invMass; rz[tid] += dtDrift * z * invMass;
@@ -76,19 +76,19 @@ void AdvanceVelocityVelocityPosition(double* __restrict__ rx, double* __restrict
 
 // ---- energy: stage 1 = per-block partial sums in a fixed order, stage 2 = one block adds the partials --------
 __global__ __launch_bounds__(256)
-void ReduceEnergyPartial(const double* __restrict__ e, const double* __restrict__ px, const double* __restrict__ py,
-                         const double* __restrict__ pz, const int* __restrict__ iSpecies,
-                         const double* __restrict__ speciesMass, const int* __restrict__ nAtoms,
-                         int nLocalBoxes, int cap, double* __restrict__ partial)
+void ReduceEnergyPartial(const real_t* __restrict__ e, const real_t* __restrict__ px, const real_t* __restrict__ py,
+                         const real_t* __restrict__ pz, const int* __restrict__ iSpecies,
+                         const real_t* __restrict__ speciesMass, const int* __restrict__ nAtoms,
+                         int nLocalBoxes, int cap, real_t* __restrict__ partial)
 {
-   __shared__ double sE[4], sK[4];
-   double accE = 0.0, accK = 0.0;
+   __shared__ real_t sE[4], sK[4];
+   real_t accE = R(0.0), accK = R(0.0);
    const long nSlots = (long)nLocalBoxes * cap;
    for (long s = (long)blockIdx.x * blockDim.x + threadIdx.x; s < nSlots; s += (long)gridDim.x * blockDim.x) {
       const int c = (int)(s / cap);
       if ((int)(s - (long)c * cap) < nAtoms[c]) {
          accE += e[s];
-         accK += (px[s]*px[s] + py[s]*py[s] + pz[s]*pz[s]) * (0.5 / speciesMass[iSpecies[s]]);
+         accK += (px[s]*px[s] + py[s]*py[s] + pz[s]*pz[s]) * (R(0.5) / speciesMass[iSpecies[s]]);
       }
    }
    accE = waveSum(accE); accK = waveSum(accK);
@@ -102,10 +102,10 @@ void ReduceEnergyPartial(const double* __restrict__ e, const double* __restrict_
 }
 
 __global__ __launch_bounds__(256)
-void ReduceEnergyFinal(const double* __restrict__ partial, int nPartial, double* __restrict__ out)
+void ReduceEnergyFinal(const real_t* __restrict__ partial, int nPartial, real_t* __restrict__ out)
 {
-   __shared__ double sE[4], sK[4];
-   double accE = 0.0, accK = 0.0;
+   __shared__ real_t sE[4], sK[4];
+   real_t accE = R(0.0), accK = R(0.0);
    for (int i = threadIdx.x; i < nPartial; i += blockDim.x) { accE += partial[2*i]; accK += partial[2*i + 1]; }
    accE = waveSum(accE); accK = waveSum(accK);
    const int wave = threadIdx.x >> 6;
@@ -126,7 +126,7 @@ void SnapshotCells(int* __restrict__ nAtoms, int* __restrict__ nAtomsPrev, int* 
 }
 
 struct AtomArrays {
-   double *rx, *ry, *rz, *px, *py, *pz;
+   real_t *rx, *ry, *rz, *px, *py, *pz;
    int *gid, *spec;
 };
 
@@ -140,7 +140,7 @@ void UpdateLinkCells(AtomArrays at, int* __restrict__ nAtoms, const int* __restr
    const int c = (int)(tid / cap);
    if (c >= boxes.nLocalBoxes || (int)(tid - (long)c * cap) >= nAtomsPrev[c]) return;
    const CellGeom g = makeGeom(boxes);
-   const double x = at.rx[tid], y = at.ry[tid], z = at.rz[tid];
+   const real_t x = at.rx[tid], y = at.ry[tid], z = at.rz[tid];
    const int nb = comdBoxFromCoord(&g, x, y, z);
    if (nb == c) return;
    if (!comdCoordInHalo(&g, x, y, z)) { atomicOr(&status[1], 1); return; }     // flew past the halo: lost
@@ -168,7 +168,7 @@ void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__
    const int t = threadIdx.x;
    const size_t o = (size_t)c * cap + t;
    int key = 0x7fffffff, spec = 0;
-   double x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
+   real_t x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
    if (t < n) {
       int g = at.gid[o];
       if (g >= 0) { key = g; spec = at.spec[o]; x = at.rx[o]; y = at.ry[o]; z = at.rz[o]; px = at.px[o]; py = at.py[o]; pz = at.pz[o]; }
@@ -199,7 +199,7 @@ void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restri
    if (n > cap) n = cap;
    const size_t o = (size_t)c * cap + lane;
    int key = 0x7fffffff, spec = 0;
-   double x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
+   real_t x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
    if (lane < n) {
       const int g = at.gid[o];
       if (g >= 0) { key = g; spec = at.spec[o]; x = at.rx[o]; y = at.ry[o]; z = at.rz[o]; px = at.px[o]; py = at.py[o]; pz = at.pz[o]; }
@@ -259,7 +259,7 @@ __global__ void MirrorCounts(const int* __restrict__ d0, const int* __restrict__
 // ---- atom halo message -----------------------------------------------------------------------------------
 // Both faces of an axis phase are packed by ONE launch and unpacked by one (blockIdx.y = face of the pair): half the launches of a
 // step that is, on one rank, a string of 5-microsecond kernels.
-struct AtomPackJob { char* msg; const int* list; const int* offsets; int nCells; double sx, sy, sz; int capacityAtoms; };
+struct AtomPackJob { char* msg; const int* list; const int* offsets; int nCells; real_t sx, sy, sz; int capacityAtoms; };
 
 // gpu_redistribute.h:376-402 LoadAtomsBufferPacked: one workgroup per listed cell gathers its atoms into the SoA
 // message at offsets[cell]; positions are shifted across the periodic boundary.  blockDim.x >= cap.
@@ -277,7 +277,7 @@ void LoadAtomsBufferPacked(AtomPackJob j0, AtomPackJob j1, AtomArrays at, const 
    const int d = jb.offsets[blockIdx.x] + t;
    int* mg = (int*)(jb.msg + COMD_ATOM_MSG_HEADER);
    int* mt = mg + n;
-   double* m = (double*)(mt + n);
+   real_t* m = (real_t*)(mt + n);
    mg[d] = at.gid[o]; mt[d] = at.spec[o];
    m[d] = at.rx[o] + jb.sx; m[n + d] = at.ry[o] + jb.sy; m[2*(size_t)n + d] = at.rz[o] + jb.sz;
    m[3*(size_t)n + d] = at.px[o]; m[4*(size_t)n + d] = at.py[o]; m[5*(size_t)n + d] = at.pz[o];
@@ -298,8 +298,8 @@ void UnloadAtomsBufferPacked(AtomUnpackJob j0, AtomUnpackJob j1, AtomArrays at, 
    if (i >= n) return;
    const int* mg = (const int*)(msg + COMD_ATOM_MSG_HEADER);
    const int* mt = mg + n;
-   const double* m = (const double*)(mt + n);
-   const double x = m[i], y = m[n + i], z = m[2*(size_t)n + i];
+   const real_t* m = (const real_t*)(mt + n);
+   const real_t x = m[i], y = m[n + i], z = m[2*(size_t)n + i];
    const CellGeom g = makeGeom(boxes);
    if (!comdCoordInHalo(&g, x, y, z)) { atomicOr(&status[1], 1); return; }
    const int c = comdBoxFromCoord(&g, x, y, z);
@@ -328,10 +328,10 @@ void UnloadAtomsBufferPacked(AtomUnpackJob j0, AtomUnpackJob j1, AtomArrays at, 
 // ---- EAM force (dfEmbed) and position halo messages: gpu_redistribute.h:638-672 ------------------------------
 // blockDim.x >= cap; one workgroup per listed cell; positional (both sides hold the cell in gid order); blockIdx.y = face of the pair.
 // boundAtoms > 0: the size both ends of the message agreed on beforehand; more atoms than that cannot be sent -> status[2]
-struct SlotJob { double* buf; const int* list; const int* offsets; int nCells; int boundAtoms; double sx, sy, sz; };
+struct SlotJob { real_t* buf; const int* list; const int* offsets; int nCells; int boundAtoms; real_t sx, sy, sz; };
 
 __global__
-void LoadForceBuffer(SlotJob j0, SlotJob j1, const double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap, int* __restrict__ status)
+void LoadForceBuffer(SlotJob j0, SlotJob j1, const real_t* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap, int* __restrict__ status)
 {
    const SlotJob& jb = blockIdx.y ? j1 : j0;
    if ((int)blockIdx.x >= jb.nCells) return;
@@ -341,7 +341,7 @@ void LoadForceBuffer(SlotJob j0, SlotJob j1, const double* __restrict__ dfEmbed,
 }
 
 __global__
-void UnloadForceBuffer(SlotJob j0, SlotJob j1, double* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap)
+void UnloadForceBuffer(SlotJob j0, SlotJob j1, real_t* __restrict__ dfEmbed, const int* __restrict__ nAtoms, int cap)
 {
    const SlotJob& jb = blockIdx.y ? j1 : j0;
    if ((int)blockIdx.x >= jb.nCells) return;
@@ -351,7 +351,7 @@ void UnloadForceBuffer(SlotJob j0, SlotJob j1, double* __restrict__ dfEmbed, con
 
 // positional refresh of the halo copies between list builds (slot order == the sender's slot order); x, y, z triples in send-cell-list order
 __global__
-void LoadPositionBuffer(SlotJob j0, SlotJob j1, const double* __restrict__ rx, const double* __restrict__ ry, const double* __restrict__ rz,
+void LoadPositionBuffer(SlotJob j0, SlotJob j1, const real_t* __restrict__ rx, const real_t* __restrict__ ry, const real_t* __restrict__ rz,
                         const int* __restrict__ nAtoms, int cap, int* __restrict__ status)
 {
    const SlotJob& jb = blockIdx.y ? j1 : j0;
@@ -360,13 +360,13 @@ void LoadPositionBuffer(SlotJob j0, SlotJob j1, const double* __restrict__ rx, c
    const int c = jb.list[blockIdx.x];
    if ((int)threadIdx.x < nAtoms[c]) {
       const size_t s = (size_t)c * cap + threadIdx.x;
-      double* o = jb.buf + 3 * (size_t)(jb.offsets[blockIdx.x] + threadIdx.x);
+      real_t* o = jb.buf + 3 * (size_t)(jb.offsets[blockIdx.x] + threadIdx.x);
       o[0] = rx[s] + jb.sx; o[1] = ry[s] + jb.sy; o[2] = rz[s] + jb.sz;
    }
 }
 
 __global__
-void UnloadPositionBuffer(SlotJob j0, SlotJob j1, double* __restrict__ rx, double* __restrict__ ry, double* __restrict__ rz,
+void UnloadPositionBuffer(SlotJob j0, SlotJob j1, real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* __restrict__ rz,
                           const int* __restrict__ nAtoms, int cap)
 {
    const SlotJob& jb = blockIdx.y ? j1 : j0;
@@ -374,7 +374,7 @@ void UnloadPositionBuffer(SlotJob j0, SlotJob j1, double* __restrict__ rx, doubl
    const int c = jb.list[blockIdx.x];
    if ((int)threadIdx.x < nAtoms[c]) {
       const size_t s = (size_t)c * cap + threadIdx.x;
-      const double* o = jb.buf + 3 * (size_t)(jb.offsets[blockIdx.x] + threadIdx.x);
+      const real_t* o = jb.buf + 3 * (size_t)(jb.offsets[blockIdx.x] + threadIdx.x);
       rx[s] = o[0]; ry[s] = o[1]; rz[s] = o[2];
    }
 }

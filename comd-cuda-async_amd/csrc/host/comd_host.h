@@ -16,6 +16,13 @@
 
 #define screenOut stdout
 
+/* mytype.h:10-19: scanf format of a real_t */
+#ifdef COMD_SINGLE
+#define FMT1 "%g"
+#else
+#define FMT1 "%lg"
+#endif
+
 /* ---- constants.h:14-39 ---- */
 #define amuInKilograms  1.660538921e-27
 #define fsInSeconds     1.0e-15

@@ -74,9 +74,9 @@ static void eamReadFuncfl(EamPotential* pot, const char* dir, const char* potNam
    const real_t x0 = 0.0;
    int bufSize = nRho > nR ? nRho : nR;
    real_t* buf = (real_t*)malloc((size_t)bufSize * sizeof(real_t));
-   for (int i = 0; i < nRho; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadFuncfl(F)", potName);
+   for (int i = 0; i < nRho; ++i) if (fscanf(fp, FMT1, buf + i) != 1) fileNotFound("eamReadFuncfl(F)", potName);
    pot->f = initInterpolationObject(nRho, x0, dRho, buf);
-   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadFuncfl(Z)", potName);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, FMT1, buf + i) != 1) fileNotFound("eamReadFuncfl(Z)", potName);
    for (int i = 1; i < nR; ++i) {
       real_t r = x0 + i * dR;
       buf[i] *= buf[i] / r;
@@ -84,7 +84,7 @@ static void eamReadFuncfl(EamPotential* pot, const char* dir, const char* potNam
    }
    buf[0] = buf[1] + (buf[1] - buf[2]);
    pot->phi = initInterpolationObject(nR, x0, dR, buf);
-   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadFuncfl(rho)", potName);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, FMT1, buf + i) != 1) fileNotFound("eamReadFuncfl(rho)", potName);
    pot->rho = initInterpolationObject(nR, x0, dR, buf);
    free(buf);
    fclose(fp);
@@ -119,11 +119,11 @@ static void eamReadSetfl(EamPotential* pot, const char* dir, const char* potName
    const real_t x0 = 0.0;
    int bufSize = nRho > nR ? nRho : nR;
    real_t* buf = (real_t*)malloc((size_t)bufSize * sizeof(real_t));
-   for (int i = 0; i < nRho; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadSetfl(F)", potName);
+   for (int i = 0; i < nRho; ++i) if (fscanf(fp, FMT1, buf + i) != 1) fileNotFound("eamReadSetfl(F)", potName);
    pot->f = initInterpolationObject(nRho, x0, dRho, buf);
-   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadSetfl(rho)", potName);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, FMT1, buf + i) != 1) fileNotFound("eamReadSetfl(rho)", potName);
    pot->rho = initInterpolationObject(nR, x0, dR, buf);
-   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) fileNotFound("eamReadSetfl(phi)", potName);
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, FMT1, buf + i) != 1) fileNotFound("eamReadSetfl(phi)", potName);
    for (int i = 1; i < nR; ++i) buf[i] /= (x0 + i * dR);
    buf[0] = buf[1] + (buf[1] - buf[2]);
    pot->phi = initInterpolationObject(nR, x0, dR, buf);

@@ -92,10 +92,14 @@ void addIntParallel(int* sendBuf, int* recvBuf, int count)
 void addRealParallel(real_t* sendBuf, real_t* recvBuf, int count)
 {
    memmove(recvBuf, sendBuf, (size_t)count * sizeof(real_t));
-   if (nRanks > 1 || loopback) transport.allreduce(transport.ctx, recvBuf, count, 1);
+   if (nRanks > 1 || loopback) transport.allreduce(transport.ctx, recvBuf, count, sizeof(real_t) == sizeof(double) ? 1 : 3);
 }
 
-void addDoubleParallel(double* sendBuf, double* recvBuf, int count) { addRealParallel(sendBuf, recvBuf, count); }
+void addDoubleParallel(double* sendBuf, double* recvBuf, int count)
+{
+   memmove(recvBuf, sendBuf, (size_t)count * sizeof(double));
+   if (nRanks > 1 || loopback) transport.allreduce(transport.ctx, recvBuf, count, 1);
+}
 
 void maxIntParallel(int* sendBuf, int* recvBuf, int count)
 {

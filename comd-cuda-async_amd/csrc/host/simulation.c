@@ -419,7 +419,7 @@ void comdGridInfo(SimFlat* s, int out[6])
 }
 
 int comdSimBoxFromTuple(SimFlat* s, int ix, int iy, int iz) { return getBoxFromTuple(s->boxes, ix, iy, iz); }
-int comdSimBoxFromCoord(SimFlat* s, const double r[3]) { return getBoxFromCoord(s->boxes, r); }
+int comdSimBoxFromCoord(SimFlat* s, const double r[3]) { const real_t rr[3] = { (real_t)r[0], (real_t)r[1], (real_t)r[2] }; return getBoxFromCoord(s->boxes, rr); }
 
 /* kind 0 = atom exchange list, 1 = force send list, 2 = force receive list; list may be NULL to query the size */
 int comdFaceCells(SimFlat* s, int kind, int face, int* list)

@@ -16,10 +16,18 @@
 #define COMD_HD static inline
 #endif
 
+/* positions and cell geometry carry the build's precision (mytype.h:8-21): the cell an atom lands in is decided by real_t arithmetic,
+ * identically on the host, on the device and in the checker */
+#ifdef COMD_SINGLE
+typedef float comd_real;
+#else
+typedef double comd_real;
+#endif
+
 typedef struct CellGeom {
    int    g[3];            /* local grid */
    int    nLocal, nTotal;
-   double lmin[3], lmax[3], inv[3];
+   comd_real lmin[3], lmax[3], inv[3];
    /* optional renumbering of the LOCAL cells (space-filling curve, linkCells.c:160-178 boxIDLookUp / boxIDLookUpReverse):
     * lookup[ix + gx*(iy + gy*iz)] = cell id, reverse[id] = ix + gx*(iy + gy*iz).  NULL: natural order.  Halo cells keep their numbers. */
    const int* lookup;
@@ -44,11 +52,11 @@ COMD_HD int comdBoxFromTuple(const CellGeom* c, int ix, int iy, int iz)
 
 /* Cell that owns position (x,y,z).  Inside the local domain the result is always a local cell (an atom
  * that rounds onto the upper face stays in the last cell); at or beyond localMax it is the halo cell. */
-COMD_HD int comdBoxFromCoord(const CellGeom* c, double x, double y, double z)
+COMD_HD int comdBoxFromCoord(const CellGeom* c, comd_real x, comd_real y, comd_real z)
 {
-   int ix = (int)floor((x - c->lmin[0]) * c->inv[0]);
-   int iy = (int)floor((y - c->lmin[1]) * c->inv[1]);
-   int iz = (int)floor((z - c->lmin[2]) * c->inv[2]);
+   int ix = (int)floor((double)((x - c->lmin[0]) * c->inv[0]));
+   int iy = (int)floor((double)((y - c->lmin[1]) * c->inv[1]));
+   int iz = (int)floor((double)((z - c->lmin[2]) * c->inv[2]));
    if (x < c->lmax[0]) { if (ix == c->g[0]) ix = c->g[0] - 1; } else ix = c->g[0];
    if (y < c->lmax[1]) { if (iy == c->g[1]) iy = c->g[1] - 1; } else iy = c->g[1];
    if (z < c->lmax[2]) { if (iz == c->g[2]) iz = c->g[2] - 1; } else iz = c->g[2];
@@ -56,11 +64,11 @@ COMD_HD int comdBoxFromCoord(const CellGeom* c, double x, double y, double z)
 }
 
 /* 1 when every tuple component lies in [-1, g]: an atom further out than the halo has been lost. */
-COMD_HD int comdCoordInHalo(const CellGeom* c, double x, double y, double z)
+COMD_HD int comdCoordInHalo(const CellGeom* c, comd_real x, comd_real y, comd_real z)
 {
-   int ix = (int)floor((x - c->lmin[0]) * c->inv[0]);
-   int iy = (int)floor((y - c->lmin[1]) * c->inv[1]);
-   int iz = (int)floor((z - c->lmin[2]) * c->inv[2]);
+   int ix = (int)floor((double)((x - c->lmin[0]) * c->inv[0]));
+   int iy = (int)floor((double)((y - c->lmin[1]) * c->inv[1]));
+   int iz = (int)floor((double)((z - c->lmin[2]) * c->inv[2]));
    return ix >= -1 && iy >= -1 && iz >= -1 && ix <= c->g[0] && iy <= c->g[1] && iz <= c->g[2];
 }
 

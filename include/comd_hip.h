@@ -26,7 +26,13 @@
 extern "C" {
 #endif
 
+/* mytype.h:8-21: one build per precision.  -DCOMD_SINGLE (make PRECISION=single -> libcomd_hip_sp.so / libcomd_host_sp.so) makes every
+ * position, momentum, force, energy, table sample and message field a float, as the reference's DOUBLE_PRECISION = OFF build does. */
+#ifdef COMD_SINGLE
+typedef float real_t;
+#else
 typedef double real_t;                 /* mytype.h:16 (COMD_DOUBLE build) */
+#endif
 typedef void*  comdStream_t;
 
 typedef struct vec_t { real_t* x; real_t* y; real_t* z; } vec_t;          /* mytype.h:24-28 */
@@ -277,9 +283,9 @@ void sortAtomsGpu(SimGpu* sim, comdStream_t stream);
 
 /* ---- halo pack / unpack: gpu_kernels.h:26-72 ------------------------------------------------ */
 /* Atom message, device or host: 16-byte header {int n; int pad[3]} followed by the reference's SoA wire
- * format (gpu_kernels.cu:506-517 getAtomMsgSoAPtr): int gid[n]; int type[n]; double rx[n],ry[n],rz[n],px[n],py[n],pz[n]. */
+ * format (gpu_kernels.cu:506-517 getAtomMsgSoAPtr): int gid[n]; int type[n]; real_t rx[n],ry[n],rz[n],px[n],py[n],pz[n]. */
 #define COMD_ATOM_MSG_HEADER 16
-#define COMD_ATOM_MSG_BYTES_PER_ATOM 56
+#define COMD_ATOM_MSG_BYTES_PER_ATOM (8 + 6 * (int)sizeof(real_t))     /* 56 in the double build = sizeof(AtomMsg), haloExchange.h:32-38 */
 typedef struct AtomMsgSoA {            /* haloExchange.h AtomMsgSoA */
    int *gid, *type; real_t *rx, *ry, *rz, *px, *py, *pz;
 } AtomMsgSoA;
@@ -341,7 +347,7 @@ typedef struct CommTransportSt {
     * payload group instead of two of each.  Writes the received byte counts to nRecv[0] (recvP) and nRecv[1] (recvM). */
    void (*sendrecv2)(void* ctx, const void* sendM, int nSendM, int dstM, void* recvP, const void* sendP, int nSendP, int dstP, void* recvM,
                      int recvCap, int device, comdStream_t stream, int nRecv[2]);
-   void (*allreduce)(void* ctx, void* buf, int count, int dtype /* 0 int sum, 1 double sum, 2 int max */);
+   void (*allreduce)(void* ctx, void* buf, int count, int dtype /* 0 int sum, 1 double sum, 2 int max, 3 float sum */);
    void (*bcast)(void* ctx, void* buf, int len, int root);
    void (*barrier)(void* ctx);
    /* optional (may be NULL): the same four transfers as sendrecv2 when BOTH ends of every message already agree on its size in bytes

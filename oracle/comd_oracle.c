@@ -11,6 +11,19 @@
  */
 #include "comd_oracle.h"
 
+/* mytype.h:8-21: the arithmetic type of the run.  -DORACLE_SINGLE restates the reference's single-precision build (real_t = float; its
+ * C sources keep double literals, so mixed expressions are evaluated in double and rounded on assignment -- the same happens here).
+ * The C interface (comd_oracle.h) stays in double either way. */
+#ifdef ORACLE_SINGLE
+typedef float real_t;
+#define RFMT "%g"
+#define REFMT "%e"
+#else
+typedef double real_t;
+#define RFMT "%lg"
+#define REFMT "%le"
+#endif
+
 #include <assert.h>
 #include <math.h>
 #include <stdio.h>
@@ -35,7 +48,7 @@ static const double kBohrToAngs  = 0.52917721092;
 double oracle_lcg61(uint64_t* seed)
 {
    const uint64_t modulus = UINT64_C(2305843009213693951);           /* 2^61 - 1 */
-   const double   toUnit  = 1.0 / UINT64_C(2305843009213693951);
+   const double   toUnit  = 1.0 / UINT64_C(2305843009213693951);      /* random.c:26: double in either build */
    *seed = (*seed * UINT64_C(437799614237992725)) % modulus;          /* wraps mod 2^64 first, as the reference does */
    return *seed * toUnit;
 }
@@ -52,55 +65,56 @@ uint64_t oracle_mkSeed(uint32_t id, uint32_t callSite)
 
 double oracle_gasdev(uint64_t* seed)
 {
-   double a, b, s;
+   real_t a, b, s;
    do {
       a = 2.0 * oracle_lcg61(seed) - 1.0;
       b = 2.0 * oracle_lcg61(seed) - 1.0;
       s = a * a + b * b;
    } while (s >= 1.0 || s == 0.0);
-   return b * sqrt(-2.0 * log(s) / s);
+   const real_t g = b * sqrt(-2.0 * log(s) / s);                        /* random.c:72 returns real_t: rounded to the build's precision */
+   return g;
 }
 
 /* ---- data ---------------------------------------------------------------------------- */
 typedef struct {            /* CoMDTypes.h:169-176 + eam.c:496-519 (values[-1..n+1]) */
-   int n; double x0, invDx; double* v;   /* v points at values[0]; v[-1], v[n], v[n+1] valid */
+   int n; real_t x0, invDx; real_t* v;   /* v points at values[0]; v[-1], v[n], v[n+1] valid */
 } Table;
 
-typedef struct { int gid, type; double rx, ry, rz, px, py, pz; } AtomRec;   /* haloExchange.h:32-38 */
+typedef struct { int gid, type; real_t rx, ry, rz, px, py, pz; } AtomRec;   /* haloExchange.h:32-38 */
 
 typedef struct {
    /* decomposition.c:18-50 */
    int    coord[3];
-   double lmin[3], lmax[3], lext[3];
+   real_t lmin[3], lmax[3], lext[3];
    /* linkCells.c:122-182 */
    int    g[3], nLocal, nTotal;
-   double bsize[3], binv[3];
+   real_t bsize[3], binv[3];
    int*   nAtoms;
    /* initAtoms.c:26-60 */
    int    *gid, *spec;
-   double *r[3], *p[3], *f[3], *U, *rhobar, *dfE;
+   real_t *r[3], *p[3], *f[3], *U, *rhobar, *dfE;
    /* haloExchange.c:198-328, 345-475 */
    int    nbr[6];
-   double shift[6][3];
+   real_t shift[6][3];
    int    nAtomCells[6], *atomCells[6];
    int    nForceCells[6], *fSend[6], *fRecv[6];
    int*   nbrBoxes;          /* [nLocal*27], self first (gpu_utility.c:520-531) */
    AtomRec *sendBuf[2], *recvBuf[2]; int nSend[2], nRecv[2];
-   double  *fsend[2], *frecv[2];   int nfSend[2], nfRecv[2];
-   double ePot, eKin;
+   real_t  *fsend[2], *frecv[2];   int nfSend[2], nfRecv[2];
+   real_t ePot, eKin;
 } Rank;
 
 struct OracleSim {
    int nx, ny, nz, pg[3], nRanks, cap, doeam, nGlobal;
-   double lat, dt, gmin[3], gmax[3], gext[3];
-   double cutoff, mass;
+   real_t lat, dt, gmin[3], gmax[3], gext[3];
+   real_t cutoff, mass;
    /* LJ (ljForce.c:102-120) */
-   double sigma, epsilon;
+   real_t sigma, epsilon;
    /* EAM */
    Table phi, rho, F;
-   double *phiSpline, *rhoSpline;      /* -P (oracle_use_splines): 4 n coefficients each, else NULL */
+   real_t *phiSpline, *rhoSpline;      /* -P (oracle_use_splines): 4 n coefficients each, else NULL */
    Rank* rk;
-   double ePot, eKin, loopSeconds;
+   real_t ePot, eKin; double loopSeconds;
 };
 
 static double wallSeconds(void)
@@ -124,7 +138,7 @@ static int boxFromTuple(const Rank* k, int ix, int iy, int iz)
 }
 
 /* ---- linkCells.c:448-480 getBoxFromCoord (tie rules included) ------------------------ */
-static int boxFromCoord(const Rank* k, const double r[3])
+static int boxFromCoord(const Rank* k, const real_t r[3])
 {
    int t[3];
    for (int a = 0; a < 3; ++a) {
@@ -144,7 +158,7 @@ static void localTuple(const Rank* k, int iBox, int* ix, int* iy, int* iz)
 }
 
 /* ---- linkCells.c:216-248 putAtomInBox ------------------------------------------------- */
-static int putAtom(OracleSim* s, Rank* k, int gid, int type, const double r[3], const double p[3])
+static int putAtom(OracleSim* s, Rank* k, int gid, int type, const real_t r[3], const real_t p[3])
 {
    int b = boxFromCoord(k, r);
    if (k->nAtoms[b] >= s->cap) {
@@ -212,25 +226,25 @@ static void buildHaloLists(Rank* k)
 }
 
 /* ---- eam.c:496-519 initInterpolationObject, :557-579 interpolate ----------------------- */
-static void tableInit(Table* t, int n, double x0, double dx, const double* data)
+static void tableInit(Table* t, int n, real_t x0, real_t dx, const real_t* data)
 {
-   double* raw = (double*)calloc((size_t)n + 3, sizeof(double));
+   real_t* raw = (real_t*)calloc((size_t)n + 3, sizeof(real_t));
    t->v = raw + 1; t->n = n; t->x0 = x0; t->invDx = 1.0 / dx;
    for (int i = 0; i < n; ++i) t->v[i] = data[i];
    t->v[-1] = t->v[0];
    t->v[n] = t->v[n-1]; t->v[n+1] = t->v[n-1];
 }
 
-static inline void tableEval(const Table* t, double x, double* f, double* df)
+static inline void tableEval(const Table* t, real_t x, real_t* f, real_t* df)
 {
-   const double* v = t->v;
+   const real_t* v = t->v;
    if (x < t->x0) x = t->x0;
    x = (x - t->x0) * t->invDx;
    int i = (int)floor(x);
    if (i > t->n) { i = t->n; x = t->n / t->invDx; }
    x = x - floor(x);
-   double g1 = v[i+1] - v[i-1];
-   double g2 = v[i+2] - v[i];
+   real_t g1 = v[i+1] - v[i-1];
+   real_t g2 = v[i+2] - v[i];
    *f  = v[i] + 0.5 * x * (g1 + x * (v[i+1] + v[i-1] - 2.0 * v[i]));
    *df = 0.5 * (g1 + x * (g2 - g1)) * t->invDx;
 }
@@ -249,18 +263,18 @@ static int readFuncfl(OracleSim* s, const char* dir, const char* name)
    if (!fgets(line, sizeof line, fp) || sscanf(line, "%d %le %d %le %le", &nRho, &dRho, &nR, &dR, &rc) != 5) { fclose(fp); return -1; }
    s->lat = lat; s->mass = amu * kAmuToInternalMass; s->cutoff = rc;
    int nb = nRho > nR ? nRho : nR;
-   double* buf = (double*)malloc((size_t)nb * sizeof(double));
-   for (int i = 0; i < nRho; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   real_t* buf = (real_t*)malloc((size_t)nb * sizeof(real_t));
+   for (int i = 0; i < nRho; ++i) if (fscanf(fp, RFMT, buf + i) != 1) { fclose(fp); free(buf); return -1; }
    tableInit(&s->F, nRho, 0.0, dRho, buf);
-   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, RFMT, buf + i) != 1) { fclose(fp); free(buf); return -1; }
    for (int i = 1; i < nR; ++i) {            /* Z(r) -> phi(r) = Z^2/r in eV */
-      double r = 0.0 + i * dR;
+      real_t r = 0.0 + i * dR;
       buf[i] *= buf[i] / r;
       buf[i] *= kHartreeToEv * kBohrToAngs;
    }
    buf[0] = buf[1] + (buf[1] - buf[2]);
    tableInit(&s->phi, nR, 0.0, dR, buf);
-   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, RFMT, buf + i) != 1) { fclose(fp); free(buf); return -1; }
    tableInit(&s->rho, nR, 0.0, dR, buf);
    free(buf); fclose(fp);
    return 0;
@@ -282,12 +296,12 @@ static int readSetfl(OracleSim* s, const char* dir, const char* name)
    if (!fgets(line, sizeof line, fp) || sscanf(line, "%d %le %le %15s", &z, &amu, &lat, ltype) != 4) { fclose(fp); return -1; }
    s->lat = lat; s->mass = amu * kAmuToInternalMass; s->cutoff = rc;
    int nb = nRho > nR ? nRho : nR;
-   double* buf = (double*)malloc((size_t)nb * sizeof(double));
-   for (int i = 0; i < nRho; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   real_t* buf = (real_t*)malloc((size_t)nb * sizeof(real_t));
+   for (int i = 0; i < nRho; ++i) if (fscanf(fp, RFMT, buf + i) != 1) { fclose(fp); free(buf); return -1; }
    tableInit(&s->F, nRho, 0.0, dRho, buf);
-   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, RFMT, buf + i) != 1) { fclose(fp); free(buf); return -1; }
    tableInit(&s->rho, nR, 0.0, dR, buf);
-   for (int i = 0; i < nR; ++i) if (fscanf(fp, "%lg", buf + i) != 1) { fclose(fp); free(buf); return -1; }
+   for (int i = 0; i < nR; ++i) if (fscanf(fp, RFMT, buf + i) != 1) { fclose(fp); free(buf); return -1; }
    for (int i = 1; i < nR; ++i) buf[i] /= (0.0 + i * dR);          /* the file stores r * phi(r) */
    buf[0] = buf[1] + (buf[1] - buf[2]);
    tableInit(&s->phi, nR, 0.0, dR, buf);
@@ -298,11 +312,11 @@ static int readSetfl(OracleSim* s, const char* dir, const char* name)
 /* ---- timestep.c:109-133 kineticEnergy (sum over virtual ranks = addRealParallel) -------- */
 void oracle_kinetic_energy(OracleSim* s)
 {
-   double eP = 0.0, eK = 0.0;
+   real_t eP = 0.0, eK = 0.0;
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];
-      double loc = 0.0;
-      const double halfInvMass = 0.5 / s->mass;
+      real_t loc = 0.0;
+      const real_t halfInvMass = 0.5 / s->mass;
       for (int b = 0; b < k->nLocal; ++b)
          for (int o = b * s->cap, e = o + k->nAtoms[b]; o < e; ++o)
             loc += (k->p[0][o]*k->p[0][o] + k->p[1][o]*k->p[1][o] + k->p[2][o]*k->p[2][o]) * halfInvMass;
@@ -325,7 +339,7 @@ void oracle_advance_velocity(OracleSim* s, double dt)
 
 void oracle_advance_position(OracleSim* s, double dt)
 {
-   const double invMass = 1.0 / s->mass;
+   const real_t invMass = 1.0 / s->mass;
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];
       for (int b = 0; b < k->nLocal; ++b)
@@ -342,7 +356,7 @@ static void updateLinkCells(OracleSim* s, Rank* k)
       int i = 0;
       while (i < k->nAtoms[b]) {
          int o = b * s->cap + i;
-         double r[3] = { k->r[0][o], k->r[1][o], k->r[2][o] };
+         real_t r[3] = { k->r[0][o], k->r[1][o], k->r[2][o] };
          int nb = boxFromCoord(k, r);
          if (nb == b) { ++i; continue; }
          if (k->nAtoms[nb] >= s->cap) { fprintf(stderr, "oracle: cell overflow in updateLinkCells\n"); abort(); }
@@ -388,7 +402,7 @@ static void sortCells(OracleSim* s, Rank* k)
 static int packAtoms(const OracleSim* s, const Rank* k, int face, AtomRec* buf)
 {
    int n = 0;
-   const double* sh = k->shift[face];
+   const real_t* sh = k->shift[face];
    for (int c = 0; c < k->nAtomCells[face]; ++c) {
       int b = k->atomCells[face][c];
       for (int o = b * s->cap, e = o + k->nAtoms[b]; o < e; ++o)
@@ -422,7 +436,7 @@ static void exchangeAtoms(OracleSim* s)
          for (int side = 0; side < 2; ++side)          /* unload faceM (from minus nbr) then faceP */
             for (int i = 0; i < k->nRecv[side]; ++i) {
                const AtomRec* a = &k->recvBuf[side][i];
-               double r[3] = { a->rx, a->ry, a->rz }, p[3] = { a->px, a->py, a->pz };
+               real_t r[3] = { a->rx, a->ry, a->rz }, p[3] = { a->px, a->py, a->pz };
                putAtom(s, k, a->gid, a->type, r, p);
             }
       }
@@ -440,29 +454,29 @@ void oracle_redistribute(OracleSim* s)
 /* ---- LJ: ljForce.c:146-265 maths, stencil form of gpu_lj_thread_atom.h:29-143 -------------- */
 static void ljForceRank(const OracleSim* s, Rank* k)
 {
-   const double rc2 = s->cutoff * s->cutoff;
-   const double s6 = s->sigma*s->sigma*s->sigma*s->sigma*s->sigma*s->sigma;
-   const double rc6 = s6 / (rc2*rc2*rc2);
-   const double eShift = 1.0 * rc6 * (rc6 - 1.0);                 /* POT_SHIFT 1.0 (ljForce.c:83) */
-   const double eps = s->epsilon;
+   const real_t rc2 = s->cutoff * s->cutoff;
+   const real_t s6 = s->sigma*s->sigma*s->sigma*s->sigma*s->sigma*s->sigma;
+   const real_t rc6 = s6 / (rc2*rc2*rc2);
+   const real_t eShift = 1.0 * rc6 * (rc6 - 1.0);                 /* POT_SHIFT 1.0 (ljForce.c:83) */
+   const real_t eps = s->epsilon;
    const int cap = s->cap;
-   double ePot = 0.0;
+   real_t ePot = 0.0;
 #pragma omp parallel for schedule(dynamic, 4) reduction(+:ePot)
    for (int b = 0; b < k->nLocal; ++b) {
       const int* nb = &k->nbrBoxes[b * 27];
       for (int io = b * cap, ie = io + k->nAtoms[b]; io < ie; ++io) {
-         const double xi = k->r[0][io], yi = k->r[1][io], zi = k->r[2][io];
-         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
+         const real_t xi = k->r[0][io], yi = k->r[1][io], zi = k->r[2][io];
+         real_t fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0;
          for (int q = 0; q < 27; ++q) {
             const int jb = nb[q];
             for (int jo = jb * cap, je = jo + k->nAtoms[jb]; jo < je; ++jo) {
-               double dx = xi - k->r[0][jo], dy = yi - k->r[1][jo], dz = zi - k->r[2][jo];
-               double r2 = dx*dx + dy*dy + dz*dz;
+               real_t dx = xi - k->r[0][jo], dy = yi - k->r[1][jo], dz = zi - k->r[2][jo];
+               real_t r2 = dx*dx + dy*dy + dz*dz;
                if (r2 <= rc2 && r2 > 0.0) {
-                  double ir2 = 1.0 / r2;
-                  double r6 = s6 * (ir2*ir2*ir2);
+                  real_t ir2 = 1.0 / r2;
+                  real_t r6 = s6 * (ir2*ir2*ir2);
                   e += 0.5 * (r6 * (r6 - 1.0) - eShift);
-                  double fr = r6 * ir2 * (48.0 * r6 - 24.0);
+                  real_t fr = r6 * ir2 * (48.0 * r6 - 24.0);
                   fx += fr * dx; fy += fr * dy; fz += fr * dz;
                }
             }
@@ -478,27 +492,27 @@ static void ljForceRank(const OracleSim* s, Rank* k)
 /* ---- -P: cubic splines in x = r^2 (gpu_utility.c:377-430 initSplineCoefficients, gpu_common.h:95-129 interpolateSpline) --------
  * The reference has this mode on the GPU only (its CPU eamForce always interpolates quadratically), so these two functions restate
  * device code and the results they check are PARITY-UNPINNED against reference output: none exists for -P. */
-static double* splineCoefficients(const Table* t)
+static real_t* splineCoefficients(const Table* t)
 {
-   const int n = t->n; const double x0 = t->x0, invDx = t->invDx; const double* v = t->v;
-   double* u = (double*)malloc((size_t)n * sizeof(double));
-   double* y2 = (double*)malloc((size_t)(n + 1) * sizeof(double));
+   const int n = t->n; const real_t x0 = t->x0, invDx = t->invDx; const real_t* v = t->v;
+   real_t* u = (real_t*)malloc((size_t)n * sizeof(real_t));
+   real_t* y2 = (real_t*)malloc((size_t)(n + 1) * sizeof(real_t));
    y2[0] = 0.0; u[0] = 0.0;                                  /* second derivative 0 at the first knot */
    for (int i = 1; i < n; ++i) {
-      const double xi = (x0 + i / invDx) * (x0 + i / invDx), xp = (x0 + (i - 1) / invDx) * (x0 + (i - 1) / invDx), xn = (x0 + (i + 1) / invDx) * (x0 + (i + 1) / invDx);
-      const double sig = (xi - xp) / (xn - xp), p = sig * y2[i - 1] + 2.0;
+      const real_t xi = (x0 + i / invDx) * (x0 + i / invDx), xp = (x0 + (i - 1) / invDx) * (x0 + (i - 1) / invDx), xn = (x0 + (i + 1) / invDx) * (x0 + (i + 1) / invDx);
+      const real_t sig = (xi - xp) / (xn - xp), p = sig * y2[i - 1] + 2.0;
       y2[i] = (sig - 1.0) / p;
       u[i] = (v[i + 1] - v[i]) / (xn - xi) - (v[i] - v[i - 1]) / (xi - xp);
       u[i] = (6.0 * u[i] / (xn - xp) - sig * u[i - 1]) / p;
    }
-   const double xN = (x0 + n / invDx) * (x0 + n / invDx), xNp = (x0 + (n - 1) / invDx) * (x0 + (n - 1) / invDx);
-   const double qn = 0.5, un = (-3.0 / (xN - xNp)) * (v[n] - v[n - 1]) / (xN - xNp);      /* first derivative 0 at the last knot */
+   const real_t xN = (x0 + n / invDx) * (x0 + n / invDx), xNp = (x0 + (n - 1) / invDx) * (x0 + (n - 1) / invDx);
+   const real_t qn = 0.5, un = (-3.0 / (xN - xNp)) * (v[n] - v[n - 1]) / (xN - xNp);      /* first derivative 0 at the last knot */
    y2[n] = (un - qn * u[n - 1]) / (qn * y2[n - 1] + 1.0);
    for (int i = n - 1; i >= 0; --i) y2[i] = y2[i] * y2[i + 1] + u[i];
-   double* c = (double*)malloc((size_t)4 * n * sizeof(double));
+   real_t* c = (real_t*)malloc((size_t)4 * n * sizeof(real_t));
    for (int i = 0; i < n; ++i) {
-      const double x1 = (x0 + i / invDx) * (x0 + i / invDx), x2 = (x0 + (i + 1) / invDx) * (x0 + (i + 1) / invDx);
-      const double d1 = y2[i], d2 = y2[i + 1], y1 = v[i], yy2 = v[i + 1];
+      const real_t x1 = (x0 + i / invDx) * (x0 + i / invDx), x2 = (x0 + (i + 1) / invDx) * (x0 + (i + 1) / invDx);
+      const real_t d1 = y2[i], d2 = y2[i + 1], y1 = v[i], yy2 = v[i + 1];
       c[4*i]   = 1.0 / (6.0 * (x2 - x1)) * (d2 - d1);
       c[4*i+1] = 1.0 / (2.0 * (x2 - x1)) * (x2 * d1 - x1 * d2);
       c[4*i+2] = 1.0 / (x2 - x1) * (1.0/6.0 * (-3*x2*x2 + (x2-x1)*(x2-x1)) * d1 + 1.0/6.0 * (3*x1*x1 - (x2-x1)*(x2-x1)) * d2 - y1 + yy2);
@@ -509,7 +523,7 @@ static double* splineCoefficients(const Table* t)
 }
 
 /* value and (1/r) d/dr at r^2; the interval is picked in single precision like the device code */
-static inline void splineEval(const Table* t, const double* c, double r2, double* f, double* df)
+static inline void splineEval(const Table* t, const real_t* c, real_t r2, real_t* f, real_t* df)
 {
    float r = sqrtf((float)r2);
    const float x0 = (float)t->x0, xn = (float)(t->x0 + t->n / t->invDx), invDx = (float)t->invDx, invDxXx0 = (float)(t->invDx * t->x0);
@@ -517,8 +531,8 @@ static inline void splineEval(const Table* t, const double* c, double r2, double
    r = r * invDx - invDxXx0;
    int ii = (int)floorf(r);
    if (ii > t->n - 1) ii = t->n - 1;
-   const double a = c[4*ii], b = c[4*ii+1], cc = c[4*ii+2], d = c[4*ii+3];
-   const double tmp = a * r2 + b;
+   const real_t a = c[4*ii], b = c[4*ii+1], cc = c[4*ii+2], d = c[4*ii+3];
+   const real_t tmp = a * r2 + b;
    *f = (tmp * r2 + cc) * r2 + d;
    *df = 2.0 * ((3.0 * tmp - b) * r2 + cc);
 }
@@ -526,28 +540,28 @@ static inline void splineEval(const Table* t, const double* c, double r2, double
 /* ---- EAM pass 1 and 3: eam.c:266-419 maths, stencil form of gpu_eam_thread_atom.h:32-140 ---- */
 static void eamPass(const OracleSim* s, Rank* k, int pass)
 {
-   const double rc2 = s->cutoff * s->cutoff;
+   const real_t rc2 = s->cutoff * s->cutoff;
    const int cap = s->cap;
 #pragma omp parallel for schedule(dynamic, 16)
    for (int b = 0; b < k->nLocal; ++b) {
       const int* nb = &k->nbrBoxes[b * 27];
       for (int io = b * cap, ie = io + k->nAtoms[b]; io < ie; ++io) {
-         const double xi = k->r[0][io], yi = k->r[1][io], zi = k->r[2][io];
-         double fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0;
+         const real_t xi = k->r[0][io], yi = k->r[1][io], zi = k->r[2][io];
+         real_t fx = 0.0, fy = 0.0, fz = 0.0, e = 0.0, rb = 0.0;
          if (pass == 3) { fx = k->f[0][io]; fy = k->f[1][io]; fz = k->f[2][io]; }
          for (int q = 0; q < 27; ++q) {
             const int jb = nb[q];
             for (int jo = jb * cap, je = jo + k->nAtoms[jb]; jo < je; ++jo) {
-               double dx = xi - k->r[0][jo], dy = yi - k->r[1][jo], dz = zi - k->r[2][jo];
-               double r2 = dx*dx + dy*dy + dz*dz;
+               real_t dx = xi - k->r[0][jo], dy = yi - k->r[1][jo], dz = zi - k->r[2][jo];
+               real_t r2 = dx*dx + dy*dy + dz*dz;
                if (r2 <= rc2 && r2 > 0.0 && s->phiSpline) {             /* -P: gpu_eam_thread_atom.h:104-121 */
-                  double phi, dphi, rho, drho;
+                  real_t phi, dphi, rho, drho;
                   splineEval(&s->rho, s->rhoSpline, r2, &rho, &drho);
                   if (pass == 1) { splineEval(&s->phi, s->phiSpline, r2, &phi, &dphi); e += phi; rb += rho; }
                   else           { dphi = (k->dfE[io] + k->dfE[jo]) * drho; }
                   fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
                } else if (r2 <= rc2 && r2 > 0.0) {
-                  double r = sqrt(r2), phi, dphi, rho, drho;
+                  real_t r = sqrt(r2), phi, dphi, rho, drho;
                   tableEval(&s->rho, r, &rho, &drho);
                   if (pass == 1) { tableEval(&s->phi, r, &phi, &dphi); e += phi; rb += rho; }
                   else           { dphi = (k->dfE[io] + k->dfE[jo]) * drho; }
@@ -564,10 +578,10 @@ static void eamPass(const OracleSim* s, Rank* k, int pass)
 /* ---- EAM pass 2: eam.c:352-366, gpu_eam_thread_atom.h:269-287 -------------------------------- */
 static void eamEmbed(const OracleSim* s, Rank* k)
 {
-   double ePot = 0.0;
+   real_t ePot = 0.0;
    for (int b = 0; b < k->nLocal; ++b)
       for (int o = b * s->cap, e = o + k->nAtoms[b]; o < e; ++o) {
-         double F, dF;
+         real_t F, dF;
          tableEval(&s->F, k->rhobar[o], &F, &dF);
          k->dfE[o] = dF;
          k->U[o] += F;
@@ -596,8 +610,8 @@ static void exchangeForce(OracleSim* s)
          Rank* k = &s->rk[ir];
          Rank* m = &s->rk[k->nbr[fm]];
          Rank* p = &s->rk[k->nbr[fp]];
-         memcpy(m->frecv[1], k->fsend[0], (size_t)k->nfSend[0] * sizeof(double)); m->nfRecv[1] = k->nfSend[0];
-         memcpy(p->frecv[0], k->fsend[1], (size_t)k->nfSend[1] * sizeof(double)); p->nfRecv[0] = k->nfSend[1];
+         memcpy(m->frecv[1], k->fsend[0], (size_t)k->nfSend[0] * sizeof(real_t)); m->nfRecv[1] = k->nfSend[0];
+         memcpy(p->frecv[0], k->fsend[1], (size_t)k->nfSend[1] * sizeof(real_t)); p->nfRecv[0] = k->nfSend[1];
       }
       for (int ir = 0; ir < s->nRanks; ++ir) {
          Rank* k = &s->rk[ir];
@@ -652,15 +666,15 @@ void oracle_step(OracleSim* s, int nSteps)
 /* ---- initAtoms.c:81-124 createFccLattice ---------------------------------------------------------- */
 static void createFcc(OracleSim* s, Rank* k)
 {
-   static const double basis[4][3] = { {0.25,0.25,0.25}, {0.25,0.75,0.75}, {0.75,0.25,0.75}, {0.75,0.75,0.25} };
+   static const real_t basis[4][3] = { {0.25,0.25,0.25}, {0.25,0.75,0.75}, {0.75,0.25,0.75}, {0.75,0.75,0.25} };
    int lo[3], hi[3];
    for (int a = 0; a < 3; ++a) { lo[a] = (int)floor(k->lmin[a] / s->lat); hi[a] = (int)ceil(k->lmax[a] / s->lat); }
-   const double zero[3] = { 0.0, 0.0, 0.0 };
+   const real_t zero[3] = { 0.0, 0.0, 0.0 };
    for (int ix = lo[0]; ix < hi[0]; ++ix)
       for (int iy = lo[1]; iy < hi[1]; ++iy)
          for (int iz = lo[2]; iz < hi[2]; ++iz)
             for (int ib = 0; ib < 4; ++ib) {
-               double r[3] = { (ix + basis[ib][0]) * s->lat, (iy + basis[ib][1]) * s->lat, (iz + basis[ib][2]) * s->lat };
+               real_t r[3] = { (ix + basis[ib][0]) * s->lat, (iy + basis[ib][1]) * s->lat, (iz + basis[ib][2]) * s->lat };
                if (r[0] < k->lmin[0] || r[0] >= k->lmax[0]) continue;
                if (r[1] < k->lmin[1] || r[1] >= k->lmax[1]) continue;
                if (r[2] < k->lmin[2] || r[2] >= k->lmax[2]) continue;
@@ -670,14 +684,14 @@ static void createFcc(OracleSim* s, Rank* k)
 }
 
 /* ---- initAtoms.c:162-198 setTemperature (+ setVcm :130-152, computeVcm :220-248) ------------------- */
-static void setTemperature(OracleSim* s, double temperature)
+static void setTemperature(OracleSim* s, real_t temperature)
 {
-   const double mass = s->mass;
+   const real_t mass = s->mass;
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];
       for (int b = 0; b < k->nLocal; ++b)
          for (int o = b * s->cap, e = o + k->nAtoms[b]; o < e; ++o) {
-            double sigma = sqrt(kB_eV * temperature / mass);
+            real_t sigma = sqrt(kB_eV * temperature / mass);
             uint64_t seed = oracle_mkSeed((uint32_t)k->gid[o], 123);
             k->p[0][o] = mass * sigma * oracle_gasdev(&seed);
             k->p[1][o] = mass * sigma * oracle_gasdev(&seed);
@@ -685,17 +699,17 @@ static void setTemperature(OracleSim* s, double temperature)
          }
    }
    if (temperature == 0.0) return;
-   double sum[4] = { 0, 0, 0, 0 };
+   real_t sum[4] = { 0, 0, 0, 0 };
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];
-      double loc[4] = { 0, 0, 0, 0 };
+      real_t loc[4] = { 0, 0, 0, 0 };
       for (int b = 0; b < k->nLocal; ++b)
          for (int o = b * s->cap, e = o + k->nAtoms[b]; o < e; ++o) {
             loc[0] += k->p[0][o]; loc[1] += k->p[1][o]; loc[2] += k->p[2][o]; loc[3] += mass;
          }
       for (int q = 0; q < 4; ++q) sum[q] += loc[q];
    }
-   double vShift[3] = { 0.0 - sum[0]/sum[3], 0.0 - sum[1]/sum[3], 0.0 - sum[2]/sum[3] };
+   real_t vShift[3] = { 0.0 - sum[0]/sum[3], 0.0 - sum[1]/sum[3], 0.0 - sum[2]/sum[3] };
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];
       for (int b = 0; b < k->nLocal; ++b)
@@ -703,8 +717,8 @@ static void setTemperature(OracleSim* s, double temperature)
             for (int a = 0; a < 3; ++a) k->p[a][o] += mass * vShift[a];
    }
    oracle_kinetic_energy(s);
-   double temp = (s->eKin / s->nGlobal) / kB_eV / 1.5;
-   double scale = sqrt(temperature / temp);
+   real_t temp = (s->eKin / s->nGlobal) / kB_eV / 1.5;
+   real_t scale = sqrt(temperature / temp);
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];
       for (int b = 0; b < k->nLocal; ++b)
@@ -715,7 +729,7 @@ static void setTemperature(OracleSim* s, double temperature)
 }
 
 /* ---- initAtoms.c:204-216 randomDisplacements -------------------------------------------------------- */
-static void randomDisplacements(OracleSim* s, double delta)
+static void randomDisplacements(OracleSim* s, real_t delta)
 {
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];
@@ -729,7 +743,7 @@ static void randomDisplacements(OracleSim* s, double delta)
    }
 }
 
-static double* dalloc(size_t n) { return (double*)calloc(n, sizeof(double)); }
+static real_t* dalloc(size_t n) { return (real_t*)calloc(n, sizeof(real_t)); }
 
 static void rankInit(OracleSim* s, Rank* k, int ir)
 {
@@ -743,7 +757,7 @@ static void rankInit(OracleSim* s, Rank* k, int ir)
       k->lmin[a] = s->gmin[a] +  k->coord[a]      * k->lext[a];
       k->lmax[a] = s->gmin[a] + (k->coord[a] + 1) * k->lext[a];
       k->g[a]    = (int)(k->lext[a] / s->cutoff);
-      k->bsize[a] = k->lext[a] / (double)k->g[a];
+      k->bsize[a] = k->lext[a] / (real_t)k->g[a];
       k->binv[a]  = 1.0 / k->bsize[a];
    }
    k->nLocal = k->g[0] * k->g[1] * k->g[2];
@@ -880,7 +894,7 @@ int oracle_threads(void)
 #endif
 }
 
-static double* const* vecOf(const Rank* k, int which)
+static real_t* const* vecOf(const Rank* k, int which)
 {
    return which == ORACLE_R ? k->r : which == ORACLE_P ? k->p : k->f;
 }
@@ -892,7 +906,7 @@ void oracle_gather(const OracleSim* s, int which, double* out)
       for (int b = 0; b < k->nLocal; ++b)
          for (int o = b * s->cap, e = o + k->nAtoms[b]; o < e; ++o) {
             int g = k->gid[o];
-            if (which <= ORACLE_F) { double* const* v = vecOf(k, which); for (int a = 0; a < 3; ++a) out[3*g + a] = v[a][o]; }
+            if (which <= ORACLE_F) { real_t* const* v = vecOf(k, which); for (int a = 0; a < 3; ++a) out[3*g + a] = v[a][o]; }
             else if (which == ORACLE_U)      out[g] = k->U[o];
             else if (which == ORACLE_RHOBAR) out[g] = k->rhobar[o];
             else                             out[g] = k->dfE[o];
@@ -904,7 +918,7 @@ void oracle_scatter(OracleSim* s, int which, const double* in)
 {
    for (int ir = 0; ir < s->nRanks; ++ir) {
       Rank* k = &s->rk[ir];
-      double* const* v = vecOf(k, which);
+      real_t* const* v = vecOf(k, which);
       for (int b = 0; b < k->nLocal; ++b)
          for (int o = b * s->cap, e = o + k->nAtoms[b]; o < e; ++o)
             for (int a = 0; a < 3; ++a) v[a][o] = in[3*k->gid[o] + a];
@@ -931,13 +945,14 @@ void oracle_rank_gid(const OracleSim* s, int rank, int* gid)
 void oracle_rank_array(const OracleSim* s, int rank, int which, int comp, double* out)
 {
    const Rank* k = &s->rk[rank];
-   const double* src = which <= ORACLE_F ? vecOf(k, which)[comp]
+   const real_t* src = which <= ORACLE_F ? vecOf(k, which)[comp]
                      : which == ORACLE_U ? k->U : which == ORACLE_RHOBAR ? k->rhobar : k->dfE;
-   memcpy(out, src, (size_t)k->nTotal * s->cap * sizeof(double));
+   const size_t n = (size_t)k->nTotal * s->cap;
+   for (size_t i = 0; i < n; ++i) out[i] = src[i];
 }
 
 int oracle_box_from_tuple(const OracleSim* s, int rank, int ix, int iy, int iz) { return boxFromTuple(&s->rk[rank], ix, iy, iz); }
-int oracle_box_from_coord(const OracleSim* s, int rank, const double r[3])     { return boxFromCoord(&s->rk[rank], r); }
+int oracle_box_from_coord(const OracleSim* s, int rank, const double r[3])     { const real_t rr[3] = { (real_t)r[0], (real_t)r[1], (real_t)r[2] }; return boxFromCoord(&s->rk[rank], rr); }
 
 int oracle_face_cells(const OracleSim* s, int rank, int kind, int face, int* list)
 {
@@ -951,7 +966,9 @@ int oracle_face_cells(const OracleSim* s, int rank, int kind, int face, int* lis
 int oracle_eam_interpolate(const OracleSim* s, int table, double x, double* f, double* df)
 {
    if (!s->doeam) return -1;
-   tableEval(table == 0 ? &s->phi : table == 1 ? &s->rho : &s->F, x, f, df);
+   real_t rf, rdf;
+   tableEval(table == 0 ? &s->phi : table == 1 ? &s->rho : &s->F, (real_t)x, &rf, &rdf);
+   *f = rf; *df = rdf;
    return 0;
 }
 
@@ -960,6 +977,6 @@ int oracle_eam_table(const OracleSim* s, int table, int* n, double* x0, double* 
    if (!s->doeam) return -1;
    const Table* t = table == 0 ? &s->phi : table == 1 ? &s->rho : &s->F;
    *n = t->n; *x0 = t->x0; *invDx = t->invDx;
-   if (values) memcpy(values, t->v - 1, (size_t)(t->n + 3) * sizeof(double));
+   if (values) for (int i = 0; i < t->n + 3; ++i) values[i] = t->v[i - 1];
    return 0;
 }

@@ -20,7 +20,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import __graft_entry__ as ge  # noqa: E402
 
-REC = struct.Struct("<ii6d")      # the reference's AtomMsg (haloExchange.h:32-38)
+SINGLE = os.environ.get("COMD_PRECISION", "double") == "single"
+REC = struct.Struct("<ii6f" if SINGLE else "<ii6d")      # the reference's AtomMsg (haloExchange.h:32-38), real_t fields
+import json  # noqa: E402
+TOL = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_values.json")))["tolerances_single" if SINGLE else "tolerances"]
+# after a trajectory of tens of steps round-off differences have grown: two decades on the one-evaluation bounds (both precisions)
+TRAJ_F = 100 * TOL["force_rel_to_max"]
+TRAJ_R = 1e-4 if SINGLE else 1e-10
 
 
 def host_mode(pkg, orc, transport, rank, world, grid, eam, n):
@@ -55,7 +61,7 @@ def host_mode(pkg, orc, transport, rank, world, grid, eam, n):
         return np.ctypeslib.as_array(ptr, shape=(ntot * cap,))
 
     gid, spec = view(h.gid, np.int32), view(h.iSpecies, np.int32)
-    arr = {k: view(getattr(h, k), np.float64) for k in ("rx", "ry", "rz", "px", "py", "pz")}
+    arr = {k: view(getattr(h, k), np.float32 if SINGLE else np.float64) for k in ("rx", "ry", "rz", "px", "py", "pz")}
     nat = np.ctypeslib.as_array(h.nAtoms, shape=(ntot,))
 
     # local rebinning on the host mirror (what updateLinkCellsGpu does on the device): re-insert every local atom by coordinate
@@ -132,17 +138,17 @@ def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async, trans
     if rank == 0:
         o = orc.Oracle(n, grid, eam=eam, delta=0.1)
         fo, eo = o.gather(orc.F), o.energy()
-        assert np.abs(f0 - fo).max() < 1e-11 * np.abs(fo).max()
-        assert abs(e0[0] - eo[0]) / e0[2] < 1e-11 and abs(e0[1] - eo[1]) / e0[2] < 1e-12
+        assert np.abs(f0 - fo).max() < TOL["force_rel_to_max"] * np.abs(fo).max()
+        assert abs(e0[0] - eo[0]) / e0[2] < TOL["energy_per_atom_step0"] and abs(e0[1] - eo[1]) / e0[2] < 10 * TOL["kinetic_per_atom"]
         o.step(steps)
         fo, eo = o.gather(orc.F), o.energy()
         ro = o.gather(orc.R)
         ext = n * 3.615
         d = r1 - ro
         d -= np.rint(d / ext) * ext                       # an atom may sit on either side of a periodic face
-        assert np.abs(d).max() < 1e-10
-        assert np.abs(f1 - fo).max() < 1e-9 * np.abs(fo).max()
-        assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < 2e-12
+        assert np.abs(d).max() < TRAJ_R
+        assert np.abs(f1 - fo).max() < TRAJ_F * np.abs(fo).max()
+        assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < TOL["energy_per_atom_trace"]
         if method.endswith("_nl"):
             assert 1 < sim.nl_builds < steps, sim.nl_builds
         print(f"gpu-mode OK: {world} ranks {grid}, {'EAM' if eam else 'LJ'} {n}^3 {method} async={use_async}: E/atom {(e1[0]+e1[1])/e1[2]:.12f}, "
@@ -165,12 +171,12 @@ def rccl_loopback_mode(pkg, orc, eam, n, method, use_async):
     sim = pkg.Simulation(args)
     o = orc.Oracle(n, eam=eam, delta=0.1)
     fo = o.gather(orc.F)
-    assert np.abs(sim.gather(2) - fo).max() < 1e-11 * np.abs(fo).max()
+    assert np.abs(sim.gather(2) - fo).max() < TOL["force_rel_to_max"] * np.abs(fo).max()
     sim.step(steps)
     o.step(steps)
     e1, eo, fo = sim.energy(), o.energy(), o.gather(orc.F)
-    assert np.abs(sim.gather(2) - fo).max() < 1e-9 * np.abs(fo).max()
-    assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < 2e-12
+    assert np.abs(sim.gather(2) - fo).max() < TRAJ_F * np.abs(fo).max()
+    assert abs((e1[0] + e1[1]) - (eo[0] + eo[1])) / e1[2] < TOL["energy_per_atom_trace"]
     sim.sum_atoms()
     assert sim.energy()[2] == 4 * n ** 3
     sim.close()

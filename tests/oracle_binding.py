@@ -18,7 +18,8 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.join(ROOT, "oracle", "liboracle.so")
+    # COMD_PRECISION=single: the restatement of the reference's single-precision build (real_t = float), same C interface
+    path = os.path.join(ROOT, "oracle", "liboracle_sp.so" if os.environ.get("COMD_PRECISION", "double") == "single" else "liboracle.so")
     if not os.path.exists(path):
         raise ImportError(f"{path} missing: run `make -C {os.path.join(ROOT, 'oracle')}`")
     L = ctypes.CDLL(path)

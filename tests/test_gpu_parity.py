@@ -13,7 +13,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_values.json")))
-TOL = G["tolerances"]
+SINGLE = os.environ.get("COMD_PRECISION", "double") == "single"      # the float build: its own checker build, its own (stated) tolerances
+TOL = G["tolerances_single" if SINGLE else "tolerances"]
 S = G["survey_recorded"]
 METHODS = ["thread_atom", "cta_cell"]
 
@@ -40,10 +41,10 @@ def test_forces_match_oracle(gpu, orc, method, eam, n, delta):
         assert np.abs(e - eo).max() <= TOL["per_atom_energy_abs"]
         ep, ek, ng = sim.energy()
         op, ok = o.energy()
-        assert abs(ep - op) / ng < TOL["energy_per_atom_step0"] and abs(ek - ok) / ng < 1e-13
+        assert abs(ep - op) / ng < TOL["energy_per_atom_step0"] and abs(ek - ok) / ng < TOL["kinetic_per_atom"]
         if eam:
-            assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < 1e-12
-            assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < 1e-12
+            assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < TOL["eam_density_abs"]
+            assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < TOL["eam_dfembed_abs"]
 
 
 @pytest.mark.parametrize("method", METHODS)
@@ -57,8 +58,8 @@ def test_eam_any_cell_capacity(gpu, orc, method, cap):
         fo = o.gather(orc.F)
         assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * np.abs(fo).max()
         assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
-        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < 1e-12
-        assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < 1e-12
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < TOL["eam_density_abs"]
+        assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < TOL["eam_dfembed_abs"]
         sim.step(10)
         o.step(10)
         (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
@@ -266,7 +267,7 @@ def test_setfl_forces_match_oracle(gpu, orc, method):
         fo = o.gather(orc.F)
         assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
         assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
-        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < 1e-12
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < TOL["eam_density_abs"]
         sim.step(20)
         o.step(20)
         (ep, ek, ng), (op, ok) = sim.energy(), o.energy()
@@ -318,8 +319,8 @@ def test_redistribution_is_bit_exact(gpu, orc, eam, n, shift):
         _assert_cells_equal(c, oc, sim.n_total_boxes)
         moved = sum(int(c["nAtoms"][b]) for b in range(sim.n_local_boxes))
         assert moved == sim.n_global
-        assert abs(sim.energy()[0] - u0) < 1e-11 * abs(u0)
-        assert np.abs(sim.gather(2) - f0).max() < 1e-10 * np.abs(f0).max()
+        assert abs(sim.energy()[0] - u0) < 0.1 * TOL["translation_invariance_rel"] * abs(u0)
+        assert np.abs(sim.gather(2) - f0).max() < TOL["translation_invariance_rel"] * np.abs(f0).max()
 
 
 def test_halo_cells_are_periodic_images(gpu):
@@ -340,7 +341,7 @@ def test_halo_cells_are_periodic_images(gpu):
             for i, gid in enumerate(g):
                 d = np.array([c["rx"][b, i], c["ry"][b, i], c["rz"][b, i]]) - np.array(local[int(gid)])
                 k = np.rint(d / ext)
-                assert np.abs(d - k * ext).max() < 1e-12 and np.abs(k).max() == 1
+                assert np.abs(d - k * ext).max() < TOL["position_abs"] and np.abs(k).max() == 1
                 n_halo += 1
         assert n_halo > sim.n_global          # 8^3 EAM: the halo shell holds more images than there are atoms
 
