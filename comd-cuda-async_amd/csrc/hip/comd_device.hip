@@ -607,7 +607,7 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
 #define COMD_LAUNCH_EAM_CTA(TAB, SPL) do { \
          static size_t attrSet = 0; \
          if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, TAB, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; } \
-         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, TAB, SPL>), dim3(grid), dim3(64 * waves), lds, st, a, stencil, rows, sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->status); } while (0)
+         hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, TAB, SPL>), dim3(grid), dim3(64 * waves), lds, st, a, stencil, rows, sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->fuseEmbed, sim->status); } while (0)
       if (spline)           COMD_LAUNCH_EAM_CTA(false, true);
       else if (tablesInLds) COMD_LAUNCH_EAM_CTA(true, false);
       else                  COMD_LAUNCH_EAM_CTA(false, false);
@@ -624,8 +624,9 @@ extern "C" void eamForce1GpuAsync(SimGpu* sim, int num_cells, int* cells_list, i
 
 extern "C" void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline)
 {
-   (void)spline; (void)method;              /* F(rhobar) is quadratic in both modes (gpu_utility.c:443) */
+   (void)spline;                            /* F(rhobar) is quadratic in both modes (gpu_utility.c:443) */
    if (num_cells <= 0) return;
+   if (sim->fuseEmbed && method == CTA_CELL) return;      /* eamForce1Gpu[Async] has done it for these cells (SimGpu.fuseEmbed) */
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
    ForceTimer timer(sim, S(stream));
    hipLaunchKernelGGL(EAM_Force_embed, dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, S(stream), a);

@@ -128,7 +128,7 @@ void EAM_Force_embed(EamArgs a)
 // A cell whose 27-cell stencil does not fit a wave's LDS slice (small boxes have larger cells) is handled by the same wave of
 // EAM_Force_cta_cell (nl_kernels.h) in the thread-per-atom form: lane = i atom, neighbours streamed from global memory, same tables.
 template <int STEP, bool SPLINE>
-__device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int lane, const TableView& rhoT, const TableView& phiT, bool sameGrid)
+__device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int lane, const TableView& rhoT, const TableView& phiT, bool sameGrid, int fuseEmbed)
 {
    const int ni = a.nAtoms[iBox];
    const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
@@ -168,7 +168,11 @@ __device__ __forceinline__ void eamCellDirect(const EamArgs& a, int iBox, int la
          }
       }
       a.fx[iOff] = fx; a.fy[iOff] = fy; a.fz[iOff] = fz;
-      if (STEP == 1) { a.e[iOff] = R(0.5) * e; a.rhobar[iOff] = rb; }
+      if (STEP == 1) {
+         real_t ei = R(0.5) * e;
+         if (fuseEmbed) { real_t F, dF; interpolate(makeTable(a.f, a.f.values), rb, F, dF); a.dfEmbed[iOff] = dF; ei += F; }
+         a.e[iOff] = ei; a.rhobar[iOff] = rb;
+      }
    }
 }
 

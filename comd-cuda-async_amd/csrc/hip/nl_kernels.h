@@ -712,7 +712,7 @@ __host__ __device__ static inline size_t eamCtaWaveBytes(int rec, int stencilAto
 template <int STEP, bool LDS_TABLES, bool SPLINE>
 __global__ __launch_bounds__(512)
 void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* __restrict__ rowsG, unsigned short* __restrict__ rowCountG,
-                        int* __restrict__ status)
+                        int fuseEmbed, int* __restrict__ status)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int REC = 3;                                    // doubles per staged atom: x, y, z (24-byte stride: conflict-free wave-wide reads);
@@ -839,7 +839,7 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
          issueLoads();
       }
       if (!fits) {      // a stencil larger than the LDS slice (small boxes have larger cells): thread-per-atom form, same tables
-         eamCellDirect<STEP, SPLINE>(a, iBox, lane, rhoT, phiT, sameGrid);
+         eamCellDirect<STEP, SPLINE>(a, iBox, lane, rhoT, phiT, sameGrid, fuseEmbed);
          __builtin_amdgcn_wave_barrier();
          continue;
       }
@@ -971,8 +971,16 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
             }
          }
          if (have && q == 0) {
-            if (STEP == 1) { a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = R(0.5) * e; a.rhobar[io] = rb; }
-            else           { a.fx[io] = f0x + fx; a.fy[io] = f0y + fy; a.fz[io] = f0z + fz; }
+            if (STEP == 1) {
+               real_t ei = R(0.5) * e;
+               if (fuseEmbed) {                               // pass 2 for this atom (EAM_Force_embed): needs only its own rhobar
+                  real_t F, dF;
+                  interpolate(makeTable(a.f, a.f.values), rb, F, dF);
+                  a.dfEmbed[io] = dF;
+                  ei += F;
+               }
+               a.fx[io] = fx; a.fy[io] = fy; a.fz[io] = fz; a.e[io] = ei; a.rhobar[io] = rb;
+            } else { a.fx[io] = f0x + fx; a.fy[io] = f0y + fy; a.fz[io] = f0z + fz; }
          }
          __builtin_amdgcn_wave_barrier();
       }

@@ -219,31 +219,43 @@ void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restri
 
 // ---- exclusive scan of nAtoms over cell lists (gpu_kernels.cu:357-407 fill + scan) -----------------------------
 // Workgroup b serves job b: out[i] = sum_{k<i} nAtoms[list[k]], out[n] = total (also copied to *total when given: the count header of
-// an atom message).  One pass: each of the 1024 threads sums a run of consecutive cells, one block scan orders the runs, the
-// thread rewrites its run.  (Round 1 walked the list 1024 cells at a time behind three barriers each: 15 us for a face of 7200 cells.)
+// an atom message).  The occupancies are fetched into the LDS first -- list entry, then the cell it names, every load independent and
+// coalesced -- and scanned from there 1024 at a time; a scan that chases list[i] -> nAtoms[...] inside its loop pays two dependent
+// global round trips per 1024 cells (15 us for a face of 7200 cells).
 struct ScanJobs { const int* list[12]; int n[12]; int* out[12]; int* total[12]; };
 
+#define SCAN_LDS_CELLS 12288              // occupancies staged per pass (48 KB); longer lists take several passes with a carry
 __global__ __launch_bounds__(1024)
 void ScanCellCountsBatch(const int* __restrict__ nAtoms, ScanJobs jobs)
 {
+   __shared__ int sCnt[SCAN_LDS_CELLS];
    __shared__ int sWave[16];
    const int* __restrict__ list = jobs.list[blockIdx.x];
    const int n = jobs.n[blockIdx.x];
    int* __restrict__ out = jobs.out[blockIdx.x];
    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-   const int run = (n + 1023) >> 10;
-   const int lo = threadIdx.x * run, hi = lo + run < n ? lo + run : n;
-   int mine = 0;
-   for (int i = lo; i < hi; ++i) mine += nAtoms[list ? list[i] : i];
-   int incl = mine;
+   int carry = 0;                                             // the same in every thread
+   for (int p0 = 0; p0 < n; p0 += SCAN_LDS_CELLS) {
+      const int m = n - p0 < SCAN_LDS_CELLS ? n - p0 : SCAN_LDS_CELLS;
+      // every occupancy of the pass with independent, coalesced loads (the list, then the cells it names): one memory round trip
+      for (int i = threadIdx.x; i < m; i += 1024) sCnt[i] = nAtoms[list ? list[p0 + i] : p0 + i];
+      __syncthreads();
+      for (int base = 0; base < m; base += 1024) {
+         const int i = base + threadIdx.x;
+         const int v = i < m ? sCnt[i] : 0;
+         int incl = v;
 #pragma unroll
-   for (int d = 1; d < 64; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-   if (lane == 63) sWave[wave] = incl;
-   __syncthreads();
-   int before = incl - mine;
-   for (int w = 0; w < wave; ++w) before += sWave[w];
-   for (int i = lo; i < hi; ++i) { out[i] = before; before += nAtoms[list ? list[i] : i]; }
-   if (threadIdx.x == 1023) { out[n] = before; if (jobs.total[blockIdx.x]) *jobs.total[blockIdx.x] = before; }
+         for (int d = 1; d < 64; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+         if (lane == 63) sWave[wave] = incl;
+         __syncthreads();
+         int before = carry, all = 0;
+         for (int w = 0; w < 16; ++w) { const int t = sWave[w]; if (w < wave) before += t; all += t; }
+         if (i < m) out[p0 + i] = before + incl - v;
+         carry += all;
+         __syncthreads();
+      }
+   }
+   if (threadIdx.x == 0) { out[n] = carry; if (jobs.total[blockIdx.x]) *jobs.total[blockIdx.x] = carry; }
 }
 
 // four message counts of an axis phase -> pinned host memory (read by the host one step later, behind an event)

@@ -198,6 +198,9 @@ SimFlat* initSimulation(Command cmd)
    cfg.latticeConstant = cmd.lat < 0.0 ? sim->pot->lat : cmd.lat;
    AllocateGpu(&sim->gpu, &cfg);
    free(nbrTable);
+   /* cta_cell: pass 1 applies the embedding function to the atoms it has just summed rhobar for; eamForce2Gpu then has nothing left to do.
+    * Not in profiling mode (-s), which runs pass 1 alone and expects the reference's pass-1 state. */
+   sim->gpu.fuseEmbed = cmd.doeam && sim->method == CTA_CELL && !sim->gpuProfile;
 
    sim->atomExchange = initAtomHaloExchange(sim->domain, sim->boxes, 1);
    if (cmd.doeam) ((EamPotential*)sim->pot)->forceExchange = initForceHaloExchange(sim->domain, sim->boxes, 1);

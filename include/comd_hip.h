@@ -154,6 +154,9 @@ typedef struct SimGpu {
                                         * (the size both ends of a halo message agreed on beforehand, see CommTransport.sendrecv2sized) */
    void*        timing;                /* comdForceTiming*: event pool of this simulation, NULL = off */
    real_t       latticeConstant;       /* GpuConfig.latticeConstant (0: 3.615): density estimate behind the LDS sizing of the cell kernels */
+   int          fuseEmbed;             /* host switch, default 0: with method CTA_CELL eamForce1Gpu[Async] also does the work of eamForce2Gpu[Async] for the
+                                        * cells it covers (F(rhobar), F'(rhobar) need nothing but the atom's own rhobar) and eamForce2Gpu[Async] returns at
+                                        * once -- same e[], dfEmbed[] after the pair of calls, one launch fewer */
    /* fields the reference's host code assigns (timestep.c:229-236); kept so that those statements compile, not read by the library */
    HashTableGpu d_hashTable;
    int          genPairlist;
