@@ -110,13 +110,16 @@ def cpu_baseline(pot, seconds):
 
 
 def measured_traffic(pot, method, nx):
-    """HBM-side bytes per force evaluation from the committed rocprofv3 PMC passes (profiles/r01_traffic.json), or None.
+    """HBM-side bytes per force evaluation from the committed rocprofv3 PMC passes (profiles/r02_traffic.json), or None.
     PMC counters cannot be read from inside the timed process, so the last profiled value for this workload is reported."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        rec = json.load(open(path)).get(f"{pot}/{method}/{nx}")
-    except (OSError, ValueError):
-        return None
+    rec = None
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", name))).get(f"{pot}/{method}/{nx}")
+        except (OSError, ValueError):
+            rec = None
+        if rec:
+            break
     if not rec:
         return None
     return (rec["fetch_KiB"] + rec["write_KiB"]) * 1024.0

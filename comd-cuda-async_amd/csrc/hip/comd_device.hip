@@ -549,10 +549,7 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
    if (spline) {
       // -P (gpu_kernels.cu:164-226): cubic splines in r^2 for phi and rho, coefficient tables read through L2 (16 KB each for funcfl)
       if (!a.phiS.coefficients || !a.rhoS.coefficients) { fprintf(stderr, "eamForce: spline != 0 but no spline tables were given to AllocateGpu\n"); exit(-1); }
-      if (method != CTA_CELL && method != THREAD_ATOM && method != WARP_ATOM) {
-         fprintf(stderr, "eamForce: the spline tables (-P) are implemented for the cell methods (thread_atom, cta_cell)\n"); exit(-1);
-      }
-      if (method != CTA_CELL) {
+      if (method == THREAD_ATOM || method == WARP_ATOM) {
          launchEamThreadAtom<STEP>(sim, a, num_cells, st, true);
          return;
       }
@@ -562,18 +559,25 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       (void)nlView(sim);
       NlSlabView v; v.list = n->list16; v.count = n->nNeighbors; v.rows = n->slabRows;
       const bool sameGrid = a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
-      const size_t lds = eamNlLdsBytes(STEP, a.rho.n, a.phi.n, sameGrid, n->maxSlabAtoms);
+      const size_t lds = eamNlLdsBytes(STEP, a.rho.n, a.phi.n, sameGrid, n->maxSlabAtoms, spline != 0);
       if (lds > 160 * 1024) { fprintf(stderr, "eamForce: %d atoms in a 27-cell stencil do not fit the LDS\n", n->maxSlabAtoms); exit(-1); }
-      static size_t attrSet = 0;
-      if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_nl_lds<STEP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
       const int grid = ceilDiv(num_cells, EAM_NL_WAVES * 8);        // each wave walks ~8 consecutive cells
-      hipLaunchKernelGGL(EAM_Force_nl_lds<STEP>, dim3(grid), dim3(64 * EAM_NL_WAVES), lds, st, a, v, n->maxSlabAtoms);
+      if (spline) {
+         static size_t attrSet = 0;
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_nl_lds<STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         hipLaunchKernelGGL((EAM_Force_nl_lds<STEP, true>), dim3(grid), dim3(64 * EAM_NL_WAVES), lds, st, a, v, n->maxSlabAtoms);
+      } else {
+         static size_t attrSet = 0;
+         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_nl_lds<STEP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         hipLaunchKernelGGL((EAM_Force_nl_lds<STEP, false>), dim3(grid), dim3(64 * EAM_NL_WAVES), lds, st, a, v, n->maxSlabAtoms);
+      }
    } else if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
       const NlView nl = nlView(sim);
       const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
       const unsigned nBlocks = (unsigned)ceilDiv((long)num_cells * sim->maxAtoms, 256);
-      if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
-      else                         hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
+      if (spline)                       hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false, true>), dim3(nBlocks), dim3(256), 0, st, a, nl);
+      else if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true, false>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
+      else                              hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
    } else if (method == CTA_CELL) {
       // wave per cell, neighbour rows built on the fly in the LDS (nl_kernels.h EAM_Force_cta_cell); any cell capacity
       const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);

@@ -116,7 +116,7 @@ void LJ_Force_thread_atom_nl(LjArgs a, NlView nl)
 }
 
 // ---- EAM passes 1 and 3 over the list; tables in LDS when they fit (funcfl), else through L2 (setfl) ----------------------------
-template <int STEP, bool LDS_TABLES>
+template <int STEP, bool LDS_TABLES, bool SPLINE>
 __global__ __launch_bounds__(256)
 void EAM_Force_thread_atom_nl(EamArgs a, NlView nl)
 {
@@ -157,18 +157,24 @@ void EAM_Force_thread_atom_nl(EamArgs a, NlView nl)
       for (int u = 0; u < 4; ++u) {
          const real_t r2 = dx[u]*dx[u] + dy[u]*dy[u] + dz[u]*dz[u];
          if (r2 <= a.rc2 && r2 > R(0.0)) {
-            const real_t ir = rsqrtR(r2), r = r2 * ir;
             real_t rho, drho, dphi;
-            if (STEP == 1) {
-               real_t phi;
-               if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
-               else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
-               e += phi; rb += rho;
+            if (SPLINE) {
+               interpolateSpline(a.rhoS, r2, rho, drho);
+               if (STEP == 1) { real_t phi; interpolateSpline(a.phiS, r2, phi, dphi); e += phi; rb += rho; }
+               else           { dphi = (dfi + dfj[u]) * drho; }
             } else {
-               interpolate(rhoT, r, rho, drho);
-               dphi = (dfi + dfj[u]) * drho;
+               const real_t ir = rsqrtR(r2), r = r2 * ir;
+               if (STEP == 1) {
+                  real_t phi;
+                  if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
+                  else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
+                  e += phi; rb += rho;
+               } else {
+                  interpolate(rhoT, r, rho, drho);
+                  dphi = (dfi + dfj[u]) * drho;
+               }
+               dphi *= ir;
             }
-            dphi *= ir;
             fx -= dphi * dx[u]; fy -= dphi * dy[u]; fz -= dphi * dz[u];
          }
       }
@@ -487,18 +493,19 @@ __host__ __device__ static inline size_t eamNlWaveBytes(int rec, int stencilAtom
    return ((size_t)rec * stencilAtoms * sizeof(real_t) + 256 + 16 * 64 * 2 + 15) & ~(size_t)15;      // records, [32] offsets + [32] cells, [16][64] row stash
 }
 
-template <int STEP>
+template <int STEP, bool SPLINE>
 __global__ __launch_bounds__(64 * EAM_NL_WAVES)
 void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
 {
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int REC = (STEP == 3) ? 4 : 3;                  // doubles per staged atom: x, y, z [, F']
    const int nRhoPad = a.rho.n + 3;
-   const bool sameGrid = (STEP == 1) && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+   const bool sameGrid = !SPLINE && (STEP == 1) && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
    real_t* sRho = (real_t*)ldsRaw;                           // pass 1 on one r grid: interleaved {phi, rho}; else rho then phi
    real_t* sPhi = sRho + nRhoPad;
-   const int tableDoubles = (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;
-   if (sameGrid) {
+   const int tableDoubles = SPLINE ? 0 : (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;      // -P: spline coefficients stay in L2
+   if (SPLINE) {
+   } else if (sameGrid) {
       for (int t = threadIdx.x; t < nRhoPad; t += blockDim.x) { sRho[2 * t] = a.phi.values[t]; sRho[2 * t + 1] = a.rho.values[t]; }
    } else {
       for (int t = threadIdx.x; t < nRhoPad; t += blockDim.x) sRho[t] = a.rho.values[t];
@@ -622,18 +629,24 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
             const real_t dx = xi - r0[0], dy = yi - r0[1], dz = zi - r0[2];
             const real_t r2 = dx*dx + dy*dy + dz*dz;
             if (r2 <= a.rc2 && r2 > R(0.0)) {
-               const real_t ir = rsqrtR(r2), r = r2 * ir;
                real_t rho, drho, dphi;
-               if (STEP == 1) {
-                  real_t phi;
-                  if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
-                  else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
-                  e += phi; rb += rho;
+               if (SPLINE) {                                 // (1/r) d/dr straight from r^2
+                  interpolateSpline(a.rhoS, r2, rho, drho);
+                  if (STEP == 1) { real_t phi; interpolateSpline(a.phiS, r2, phi, dphi); e += phi; rb += rho; }
+                  else           { dphi = (dfi + r0[3 % REC]) * drho; }
                } else {
-                  interpolate(rhoT, r, rho, drho);
-                  dphi = (dfi + r0[3 % REC]) * drho;
+                  const real_t ir = rsqrtR(r2), r = r2 * ir;
+                  if (STEP == 1) {
+                     real_t phi;
+                     if (sameGrid) interpolatePair(sRho, rhoT, r, phi, dphi, rho, drho);
+                     else { interpolate(rhoT, r, rho, drho); interpolate(phiT, r, phi, dphi); }
+                     e += phi; rb += rho;
+                  } else {
+                     interpolate(rhoT, r, rho, drho);
+                     dphi = (dfi + r0[3 % REC]) * drho;
+                  }
+                  dphi *= ir;
                }
-               dphi *= ir;
                fx -= dphi * dx; fy -= dphi * dy; fz -= dphi * dz;
             }
          };
@@ -646,20 +659,33 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
             const real_t q0 = dx0*dx0 + dy0*dy0 + dz0*dz0, q1 = dx1*dx1 + dy1*dy1 + dz1*dz1;
             const bool h0 = q0 <= a.rc2 && q0 > R(0.0), h1 = two && q1 <= a.rc2 && q1 > R(0.0);
             const real_t s0 = h0 ? q0 : a.rc2, s1 = h1 ? q1 : a.rc2;
-            const real_t ir0 = rsqrtR(s0), ir1 = rsqrtR(s1);
-            const real_t d0 = s0 * ir0, d1 = s1 * ir1;
             real_t rho0, drho0, dphi0, rho1, drho1, dphi1;
-            if (STEP == 1) {
-               real_t phi0, phi1;
-               if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
-               else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
-               e += (h0 ? phi0 : R(0.0)) + (h1 ? phi1 : R(0.0));
-               rb += (h0 ? rho0 : R(0.0)) + (h1 ? rho1 : R(0.0));
+            if (SPLINE) {
+               interpolateSpline(a.rhoS, s0, rho0, drho0); interpolateSpline(a.rhoS, s1, rho1, drho1);
+               if (STEP == 1) {
+                  real_t phi0, phi1;
+                  interpolateSpline(a.phiS, s0, phi0, dphi0); interpolateSpline(a.phiS, s1, phi1, dphi1);
+                  e += (h0 ? phi0 : R(0.0)) + (h1 ? phi1 : R(0.0));
+                  rb += (h0 ? rho0 : R(0.0)) + (h1 ? rho1 : R(0.0));
+               } else {
+                  dphi0 = (dfi + r0[3 % REC]) * drho0; dphi1 = (dfi + r1[3 % REC]) * drho1;
+               }
+               dphi0 = h0 ? dphi0 : R(0.0); dphi1 = h1 ? dphi1 : R(0.0);
             } else {
-               interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
-               dphi0 = (dfi + r0[3 % REC]) * drho0; dphi1 = (dfi + r1[3 % REC]) * drho1;
+               const real_t ir0 = rsqrtR(s0), ir1 = rsqrtR(s1);
+               const real_t d0 = s0 * ir0, d1 = s1 * ir1;
+               if (STEP == 1) {
+                  real_t phi0, phi1;
+                  if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
+                  else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
+                  e += (h0 ? phi0 : R(0.0)) + (h1 ? phi1 : R(0.0));
+                  rb += (h0 ? rho0 : R(0.0)) + (h1 ? rho1 : R(0.0));
+               } else {
+                  interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
+                  dphi0 = (dfi + r0[3 % REC]) * drho0; dphi1 = (dfi + r1[3 % REC]) * drho1;
+               }
+               dphi0 = h0 ? dphi0 * ir0 : R(0.0); dphi1 = h1 ? dphi1 * ir1 : R(0.0);
             }
-            dphi0 = h0 ? dphi0 * ir0 : R(0.0); dphi1 = h1 ? dphi1 * ir1 : R(0.0);
             fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
             fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
          };
@@ -682,10 +708,10 @@ void EAM_Force_nl_lds(EamArgs a, NlSlabView nl, int stencilAtoms)
    }
 }
 
-static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, int stencilAtoms)
+static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, int stencilAtoms, bool spline)
 {
    const int rec = step == 3 ? 4 : 3;
-   const size_t tableWords = step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
+   const size_t tableWords = spline ? 0 : step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
    return eamTableBytesAligned(tableWords) + (size_t)EAM_NL_WAVES * eamNlWaveBytes(rec, stencilAtoms);
 }
 

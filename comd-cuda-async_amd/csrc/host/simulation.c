@@ -120,11 +120,9 @@ SimFlat* initSimulationHost(Command cmd)
    if (cmd.ljInterpolation) {
       printf("Error: -I is outside this build's scope (SURVEY.md section 8f).\n"); exit(-1);
    }
-   /* -P (CoMD.c:271, gpu_utility.c:474-500): cubic-spline tables in r^2 for phi and rho; the reference has them in its cell kernels */
+   /* -P (CoMD.c:271, gpu_utility.c:474-500): cubic-spline tables in r^2 for phi and rho, for every force method (gpu_kernels.cu:164-226) */
    sim->spline = cmd.spline;
-   if (sim->spline && (!cmd.doeam || (sim->method != THREAD_ATOM && sim->method != CTA_CELL))) {
-      printf("Error: -P applies to EAM with -m thread_atom or cta_cell.\n"); exit(-1);
-   }
+   if (sim->spline && !cmd.doeam) { printf("Error: -P applies to EAM (-e).\n"); exit(-1); }
    /* -L (CoMD.c:250-255, ljForce.c:141): pairlist bits for the CTA-per-cell LJ kernel; same skin, cells and rebuild rule as the lists */
    sim->usePairlist = cmd.usePairlist;
    if (sim->usePairlist && (cmd.doeam || sim->method != CTA_CELL)) { printf("Error: -L applies to LJ with -m cta_cell.\n"); exit(-1); }

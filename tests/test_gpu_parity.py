@@ -492,7 +492,7 @@ def test_hilbert_numbering_changes_nothing_but_the_cell_ids(gpu, orc, eam, n, me
 
 
 # ---------------------------------------------------------------- cubic-spline EAM tables (-P): PARITY-UNPINNED
-@pytest.mark.parametrize("method", METHODS)
+@pytest.mark.parametrize("method", METHODS + ["thread_atom_nl"])
 @pytest.mark.parametrize("n,delta", [(8, 0.0), ((7, 9, 12), 0.2)])
 def test_spline_tables_match_the_restatement(gpu, orc, method, n, delta):
     """-P evaluates phi and rho as cubic splines in r^2 (gpu_utility.c:377-430, gpu_common.h:95-129).  The reference implements this
@@ -503,7 +503,7 @@ def test_spline_tables_match_the_restatement(gpu, orc, method, n, delta):
         fo, eo = o.gather(orc.F), o.gather(orc.U)
         assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * max(np.abs(fo).max(), 1.0)
         assert np.abs(sim.gather(3) - eo).max() <= TOL["per_atom_energy_abs"]
-        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < 1e-12
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < TOL["eam_density_abs"]
         quad = orc.Oracle(n, eam=1, delta=delta)
         assert 0 < abs(o.energy()[0] - quad.energy()[0]) / o.n_global < 1e-4          # different interpolant, same potential
         sim.step(20)
