@@ -718,13 +718,13 @@ static void launchCompactSort(SimGpu* sim, int first, int nCells, hipStream_t st
 {
    if (nCells <= 0) return;
    if (sim->maxAtoms <= 64) {
-      hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4)), dim3(256), 0, st,
+      hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4 * COMPACT_RUN)), dim3(256), 0, st,
                          atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, first, nCells, sim->maxAtoms);
       LAUNCH_CHECK();
       return;
    }
-   hipLaunchKernelGGL(CompactSortCells, dim3(nCells), dim3(sortBlock(sim->maxAtoms)), (size_t)sortBlock(sim->maxAtoms) * sizeof(int), st,
-                      atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, first, sim->maxAtoms);
+   hipLaunchKernelGGL(CompactSortCells, dim3(ceilDiv(nCells, COMPACT_RUN)), dim3(sortBlock(sim->maxAtoms)), (size_t)sortBlock(sim->maxAtoms) * sizeof(int), st,
+                      atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, first, nCells, sim->maxAtoms);
    LAUNCH_CHECK();
 }
 

@@ -103,44 +103,6 @@ __device__ __forceinline__ float dppMoveR(float v)
    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
 }
 
-// sum within each row of 16 lanes; every lane of the row ends with the row total
-__device__ __forceinline__ real_t rowSum(real_t v)
-{
-   v += dppMoveR<0xB1, 0xF>(v);        // quad_perm [1,0,3,2]
-   v += dppMoveR<0x4E, 0xF>(v);        // quad_perm [2,3,0,1]
-   v += dppMoveR<0x124, 0xF>(v);       // row_ror:4
-   v += dppMoveR<0x128, 0xF>(v);       // row_ror:8
-   return v;
-}
-
-// Two atoms at once: pa / pb are per-lane partial sums of atoms A and B.  v_permlane32_swap exchanges the upper half of
-// pa with the lower half of pb, so one add leaves A's sums in lanes 0-31 and B's in lanes 32-63; rows are then summed
-// with DPP and row_bcast:15 folds row 0 into row 1 and row 2 into row 3.  Lane 31 holds A's total, lane 63 B's.
-__device__ __forceinline__ double pairSum(double pa, double pb)
-{
-   auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(pa), (unsigned)__double2loint(pb), false, false);
-   auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(pa), (unsigned)__double2hiint(pb), false, false);
-   double v = __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
-   v = rowSum(v);
-   v += dppMoveR<0x142, 0xA>(v);       // row_bcast:15 into rows 1 and 3
-   return v;
-}
-__device__ __forceinline__ float pairSum(float pa, float pb)
-{
-   auto w = __builtin_amdgcn_permlane32_swap((unsigned)__float_as_int(pa), (unsigned)__float_as_int(pb), false, false);
-   float v = __int_as_float((int)w[0]) + __int_as_float((int)w[1]);
-   v = rowSum(v);
-   v += dppMoveR<0x142, 0xA>(v);
-   return v;
-}
-
-__device__ __forceinline__ int waveSumInt(int v)
-{
-#pragma unroll
-   for (int m = 32; m >= 1; m >>= 1) v += __builtin_amdgcn_ds_bpermute((laneId() ^ m) << 2, v);
-   return v;
-}
-
 // Blocks are dealt round-robin over the 8 XCDs (block b runs on XCD b % 8).  Give each XCD one contiguous run
 // of the logical grid so that blocks sharing neighbour cells also share an L2 (bijective for any grid size).
 __device__ __forceinline__ int xcdRemap(int bid, int nBlocks)

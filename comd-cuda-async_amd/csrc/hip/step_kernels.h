@@ -154,67 +154,76 @@ void UpdateLinkCells(AtomArrays at, int* __restrict__ nAtoms, const int* __restr
    dirty[c] = 1; dirty[nb] = 1;
 }
 
-// One workgroup per cell in [first, first+n): if the cell is dirty, drop holes and rewrite the survivors in
-// ascending-gid order (rank sort: rank = number of smaller keys; gids are unique).  blockDim.x >= cap.
+// Cells [first, first + nCells), COMPACT_RUN consecutive cells per workgroup (almost all are clean: one flag read each): if a cell is
+// dirty, drop holes and rewrite the survivors in ascending-gid order (rank sort: rank = number of smaller keys; gids are unique).
+// blockDim.x >= cap.
+#define COMPACT_RUN 8
 __global__
 void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int* __restrict__ status,
-                      int first, int cap)
+                      int first, int nCells, int cap)
 {
    extern __shared__ int sKey[];
-   const int c = first + blockIdx.x;
-   if (!dirty[c]) return;
-   int n = nAtoms[c];
-   if (n > cap) n = cap;                                  // overflow already flagged by the writer
    const int t = threadIdx.x;
-   const size_t o = (size_t)c * cap + t;
-   int key = 0x7fffffff, spec = 0;
-   real_t x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
-   if (t < n) {
-      int g = at.gid[o];
-      if (g >= 0) { key = g; spec = at.spec[o]; x = at.rx[o]; y = at.ry[o]; z = at.rz[o]; px = at.px[o]; py = at.py[o]; pz = at.pz[o]; }
+   for (int k = 0; k < COMPACT_RUN; ++k) {
+      const int idx = blockIdx.x * COMPACT_RUN + k;
+      if (idx >= nCells) return;
+      const int c = first + idx;
+      if (!dirty[c]) continue;                              // workgroup-uniform
+      int n = nAtoms[c];
+      if (n > cap) n = cap;                                  // overflow already flagged by the writer
+      const size_t o = (size_t)c * cap + t;
+      int key = 0x7fffffff, spec = 0;
+      real_t x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
+      if (t < n) {
+         int g = at.gid[o];
+         if (g >= 0) { key = g; spec = at.spec[o]; x = at.rx[o]; y = at.ry[o]; z = at.rz[o]; px = at.px[o]; py = at.py[o]; pz = at.pz[o]; }
+      }
+      __syncthreads();                                       // the previous cell's keys are no longer read
+      if (t < cap) sKey[t] = key;
+      __syncthreads();
+      int rank = 0, live = 0;
+      for (int j = 0; j < n; ++j) { int kj = sKey[j]; rank += (kj < key); live += (kj != 0x7fffffff); }
+      if (key != 0x7fffffff) {
+         const size_t d = (size_t)c * cap + rank;
+         at.gid[d] = key; at.spec[d] = spec;
+         at.rx[d] = x; at.ry[d] = y; at.rz[d] = z; at.px[d] = px; at.py[d] = py; at.pz[d] = pz;
+      }
+      if (t == 0) { nAtoms[c] = live; dirty[c] = 0; }
    }
-   if (t < cap) sKey[t] = key;
-   __syncthreads();
-   int rank = 0, live = 0;
-   for (int j = 0; j < n; ++j) { int kj = sKey[j]; rank += (kj < key); live += (kj != 0x7fffffff); }
-   __syncthreads();
-   if (key != 0x7fffffff) {
-      const size_t d = (size_t)c * cap + rank;
-      at.gid[d] = key; at.spec[d] = spec;
-      at.rx[d] = x; at.ry[d] = y; at.rz[d] = z; at.px[d] = px; at.py[d] = py; at.pz[d] = pz;
-   }
-   if (t == 0) { nAtoms[c] = live; dirty[c] = 0; }
 }
 
-// Same for cap <= 64: one WAVE per cell, four cells per workgroup, keys exchanged with v_readlane (no LDS, no barrier).
+// Same for cap <= 64: one WAVE per run of COMPACT_RUN cells, four waves per workgroup, keys exchanged with v_readlane (no LDS, no barrier).
 __global__ __launch_bounds__(256)
 void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int first, int nCells, int cap)
 {
    const int lane = threadIdx.x & 63;
-   const int idx = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-   if (idx >= nCells) return;
-   const int c = first + idx;
-   if (!uniform(dirty[c])) return;
-   int n = uniform(nAtoms[c]);
-   if (n > cap) n = cap;
-   const size_t o = (size_t)c * cap + lane;
-   int key = 0x7fffffff, spec = 0;
-   real_t x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
-   if (lane < n) {
-      const int g = at.gid[o];
-      if (g >= 0) { key = g; spec = at.spec[o]; x = at.rx[o]; y = at.ry[o]; z = at.rz[o]; px = at.px[o]; py = at.py[o]; pz = at.pz[o]; }
+   const int run = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+   for (int k = 0; k < COMPACT_RUN; ++k) {
+      const int idx = run * COMPACT_RUN + k;
+      if (idx >= nCells) return;
+      const int c = first + idx;
+      if (!uniform(dirty[c])) continue;
+      int n = uniform(nAtoms[c]);
+      if (n > cap) n = cap;
+      const size_t o = (size_t)c * cap + lane;
+      int key = 0x7fffffff, spec = 0;
+      real_t x = 0, y = 0, z = 0, px = 0, py = 0, pz = 0;
+      if (lane < n) {
+         const int g = at.gid[o];
+         if (g >= 0) { key = g; spec = at.spec[o]; x = at.rx[o]; y = at.ry[o]; z = at.rz[o]; px = at.px[o]; py = at.py[o]; pz = at.pz[o]; }
+      }
+      int rank = 0, live = 0;
+      for (int j = 0; j < n; ++j) {
+         const int kj = __builtin_amdgcn_readlane(key, j);
+         rank += (kj < key); live += (kj != 0x7fffffff);
+      }
+      if (key != 0x7fffffff) {
+         const size_t d = (size_t)c * cap + rank;
+         at.gid[d] = key; at.spec[d] = spec;
+         at.rx[d] = x; at.ry[d] = y; at.rz[d] = z; at.px[d] = px; at.py[d] = py; at.pz[d] = pz;
+      }
+      if (lane == 0) { nAtoms[c] = live; dirty[c] = 0; }
    }
-   int rank = 0, live = 0;
-   for (int j = 0; j < n; ++j) {
-      const int kj = __builtin_amdgcn_readlane(key, j);
-      rank += (kj < key); live += (kj != 0x7fffffff);
-   }
-   if (key != 0x7fffffff) {
-      const size_t d = (size_t)c * cap + rank;
-      at.gid[d] = key; at.spec[d] = spec;
-      at.rx[d] = x; at.ry[d] = y; at.rz[d] = z; at.px[d] = px; at.py[d] = py; at.pz[d] = pz;
-   }
-   if (lane == 0) { nAtoms[c] = live; dirty[c] = 0; }
 }
 
 // ---- exclusive scan of nAtoms over cell lists (gpu_kernels.cu:357-407 fill + scan) -----------------------------
@@ -238,7 +247,16 @@ void ScanCellCountsBatch(const int* __restrict__ nAtoms, ScanJobs jobs)
    for (int p0 = 0; p0 < n; p0 += SCAN_LDS_CELLS) {
       const int m = n - p0 < SCAN_LDS_CELLS ? n - p0 : SCAN_LDS_CELLS;
       // every occupancy of the pass with independent, coalesced loads (the list, then the cells it names): one memory round trip
-      for (int i = threadIdx.x; i < m; i += 1024) sCnt[i] = nAtoms[list ? list[p0 + i] : p0 + i];
+      {
+         constexpr int PER = SCAN_LDS_CELLS / 1024;           // all list loads of the pass in flight, then all occupancy loads
+         int cell[PER], cnt[PER];
+#pragma unroll
+         for (int u = 0; u < PER; ++u) { const int i = threadIdx.x + 1024 * u; cell[u] = i < m ? (list ? list[p0 + i] : p0 + i) : -1; }
+#pragma unroll
+         for (int u = 0; u < PER; ++u) cnt[u] = cell[u] >= 0 ? nAtoms[cell[u]] : 0;
+#pragma unroll
+         for (int u = 0; u < PER; ++u) { const int i = threadIdx.x + 1024 * u; if (i < m) sCnt[i] = cnt[u]; }
+      }
       __syncthreads();
       for (int base = 0; base < m; base += 1024) {
          const int i = base + threadIdx.x;

@@ -173,6 +173,7 @@ typedef struct HaloSpecSt {
    int   pending;                         /* the mirror kernel has been enqueued: wait for `event` before reading */
    int*  mirror;                          /* pinned [4] */
    void* event;
+   int   haveBound, lastBound[4];         /* sizes the previous exchange was posted with: a count above its bound means that exchange was cut short */
 } HaloSpec;
 
 typedef struct HaloExchangeSt {

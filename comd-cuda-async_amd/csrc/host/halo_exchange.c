@@ -470,7 +470,7 @@ void prepareForceExchange(HaloExchange* hh, SimFlat* sim)
 }
 
 /* ---- driver -------------------------------------------------------------------------------------------------- */
-void invalidateHaloSizes(HaloExchange* hh) { for (int a = 0; a < 3; ++a) hh->spec[a].valid = 0; }
+void invalidateHaloSizes(HaloExchange* hh) { for (int a = 0; a < 3; ++a) { hh->spec[a].valid = 0; hh->spec[a].haveBound = 0; } }
 
 static int handshakeForced(void)
 {
@@ -479,10 +479,18 @@ static int handshakeForced(void)
    return cached;
 }
 
-/* transfer size both ends derive from last step's count */
+/* transfer size both ends derive from last step's count: + 12.5 % + 64 atoms.  COMD_HALO_SLACK="percent,atoms" replaces the two numbers
+ * (the tests set 0,0 to see a message outgrow its bound and the run stop) */
 static int boundOf(int last, int capacityAtoms)
 {
-   long b = (long)last + last / 8 + 64;
+   static int pct = -1, atoms = 64;
+   if (pct < 0) {
+      pct = 1250;                                          /* hundredths of a percent */
+      const char* e = getenv("COMD_HALO_SLACK");
+      double p = 0.0; int a = 0;
+      if (e && sscanf(e, "%lf,%d", &p, &a) == 2 && p >= 0.0 && a >= 0) { pct = (int)(p * 100.0 + 0.5); atoms = a; }
+   }
+   long b = (long)last + (long)last * pct / 10000 + atoms;
    return b > capacityAtoms ? capacityAtoms : (int)b;
 }
 
@@ -497,7 +505,17 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
    int bound[4] = { 0, 0, 0, 0 };
    if (useSized) {
       if (sp->pending) { comdEventSynchronize(sp->event); sp->pending = 0; }      /* recorded a whole step ago */
+      /* the previous exchange of this axis was posted with lastBound[]: a message that turned out larger was cut short (its pack kernel refused
+       * it and raised the device flag).  Both ends see the same count, so both stop here, before any later transfer is sized from diverged cells. */
+      for (int i = 0; sp->haveBound && i < 4; ++i)
+         if (sp->mirror[i] > sp->lastBound[i]) {
+            fprintf(stderr, "Rank %d: a halo message overflowed its buffer, or grew by more than 12.5 %% + 64 atoms in one step (%d atoms against an agreed %d; "
+                            "exchange %d, axis %d).  COMD_HALO_HANDSHAKE=1 exchanges exact sizes.\n", getMyRank(), sp->mirror[i], sp->lastBound[i], hh->type, iAxis);
+            exit(-1);
+         }
       for (int i = 0; i < 4; ++i) bound[i] = hh->exactCounts ? sp->mirror[i] : boundOf(sp->mirror[i], hh->capacityAtoms);
+      for (int i = 0; i < 4; ++i) sp->lastBound[i] = bound[i];
+      sp->haveBound = 1;
       if (hh->setBounds) { hh->setBounds(hh->parms, faceM, bound[0], bound[3]); hh->setBounds(hh->parms, faceP, bound[1], bound[2]); }
    }
    int nSendM, nSendP;

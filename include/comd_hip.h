@@ -143,7 +143,7 @@ typedef struct SimGpu {
    /* redistribution scratch (CoMDTypes.h:123-126 flags/tmp_sort) */
    int*         nAtomsPrev;            /* device [nTotalBoxes]: occupancy snapshot */
    int*         cellDirty;             /* device [nTotalBoxes]: membership changed, needs compaction + gid sort */
-   int*         status;                /* device [4]: {cell overflow, lost atom, msg overflow, EAM pair-queue overflow} */
+   int*         status;                /* device [4]: {cell overflow / stencil too large, lost atom, msg overflow or outgrown bound, EAM row / list overflow} */
    real_t*      reduceBuf;             /* device: per-block partial sums for computeEnergy */
    real_t*      pinned;                /* pinned host staging (energies, counts) */
    int          reduceBlocks;

@@ -186,6 +186,21 @@ def rccl_loopback_mode(pkg, orc, eam, n, method, use_async):
 
 def main():
     mode, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    if mode == "rccl_hot":
+        # a hot, strongly displaced lattice on the RCCL loopback: atoms cross cell faces every step, so the halo message counts move.
+        # No checker here: the caller looks at how the run ends (tests/test_multirank.py, the outgrown-bound test).
+        pkg = ge.load_package()
+        pkg.setup_gpu(0, 0)
+        pkg.init_parallel(0, 1, pkg.rccl_transport(0, 1, pkg.rccl_unique_id()))
+        n = int(sys.argv[9])
+        sim = pkg.Simulation(["-x", n, "-y", n, "-z", n, "-r", 0.4, "-T", 3000, "-m", sys.argv[10]] + (["-e"] if int(sys.argv[8]) else []))
+        for _ in range(8):
+            sim.step(10)
+        sim.sum_atoms()
+        assert sim.energy()[2] == 4 * n ** 3
+        sim.close()
+        print("rccl-hot run finished")
+        return
     if mode == "rccl":
         pkg, orc = ge.load_package(), ge.load_oracle()
         rccl_loopback_mode(pkg, orc, int(sys.argv[8]), int(sys.argv[9]), sys.argv[10], int(sys.argv[11]))

@@ -86,3 +86,53 @@ def test_rccl_transport_loopback(eam, n, method, use_async):
     grouped ncclSend/ncclRecv to itself), the EAM dF/drho exchange and the energy / atom-count reductions."""
     outs = _launch("rccl", (1, 1, 1), eam, n, extra=(method, use_async), env_extra={"COMD_LOOPBACK_TRANSPORT": "1"})
     assert "rccl-loopback OK" in outs[0]
+
+
+@pytest.mark.gpu
+def test_message_that_outgrows_its_agreed_size_stops_the_run():
+    """The sized protocol gives a message last step's count + 12.5 % + 64 atoms.  A hot (3000 K), strongly displaced EAM lattice moves atoms
+    across cell faces every step: with the default slack 80 steps run through; with the slack set to nothing (COMD_HALO_SLACK=0,0) the first
+    message that grows must be refused by the pack kernel, raise the device status flag, and the run must stop at the next status read with a
+    message that names the rule -- never carry on with a truncated halo."""
+    def run(extra_env):
+        env = dict(os.environ, COMD_LOOPBACK_TRANSPORT="1", OMP_NUM_THREADS="2", **extra_env)
+        proc = subprocess.run([sys.executable, os.path.join(HERE, "multirank_worker.py"), "rccl_hot", "0", "1", str(_free_port()), "1", "1", "1", "1", "10", "cta_cell", "0"],
+                              capture_output=True, text=True, env=env, timeout=600)
+        return proc.returncode, proc.stdout + proc.stderr
+    rc, out = run({})
+    assert rc == 0 and "rccl-hot run finished" in out, out[-2000:]
+    rc, out = run({"COMD_HALO_SLACK": "0,0"})
+    assert rc != 0 and "rccl-hot run finished" not in out, out[-2000:]
+    assert "halo message overflowed its buffer, or grew by more than" in out, out[-2000:]
+
+
+@pytest.mark.gpu
+def test_bench_reports_what_rccl_saw_and_maps_one_copy_of_it():
+    """bench.py imports torch (for the gloo control plane) before libcomd_hip.so, so two builds of librccl are within reach: torch's
+    bundled one and /opt/rocm's.  Exactly one may end up mapped, the communicator must report the launched rank count, and the line must
+    carry both facts (rccl_ranks, librccl) so that a SCALE record shows what carried the halo messages."""
+    import json
+    env = dict(os.environ, COMD_LOOPBACK_TRANSPORT="1", MASTER_PORT=str(_free_port()))
+    proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--nx", "20", "--steps", "3", "--warmup", "1",
+                           "--no-variants", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    cfg = line["config"]
+    assert cfg["transport"] == "rccl-loopback" and cfg["rccl_ranks"] == 1 and cfg["rank_devices"] == [0]
+    assert len(cfg["librccl"]) == 1, cfg["librccl"]
+    assert "measured" not in line
+
+
+def test_bench_refuses_to_run_many_ranks_without_rccl():
+    """Two ranks on a machine without a GPU (no device, hence no RCCL communicator): bench.py must exit non-zero on every rank instead of
+    printing a host-staged number -- a SCALE record produced that way would look measured.  Runs here, on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible: the refusal path needs a machine where RCCL cannot form")
+    port = str(_free_port())
+    procs = [subprocess.Popen([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--nx", "10", "--steps", "2", "--warmup", "1"],
+                              env=dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=port),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode != 0 for p in procs), [o[1][-500:] for o in outs]
+    assert all('"value"' not in o[0] for o in outs)
