@@ -359,7 +359,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
-                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount };
+                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1] };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
@@ -419,6 +419,7 @@ static LjArgs makeLjArgs(SimGpu* sim, int num_cells, int* cells_list)
    const double sigma = sim->lj_pot.sigma, rc = sim->lj_pot.cutoff;
    a.rc2 = rc * rc;
    a.s6 = sigma * sigma * sigma * sigma * sigma * sigma;
+   a.s6x2 = 2.0 * (sigma * sigma * sigma * sigma * sigma * sigma);
    const double rc6 = a.s6 / (a.rc2 * a.rc2 * a.rc2);
    a.eShift = rc6 * (rc6 - 1.0);                 // POT_SHIFT 1.0
    a.eps = sim->lj_pot.epsilon;
@@ -429,10 +430,69 @@ static LjArgs makeLjArgs(SimGpu* sim, int num_cells, int* cells_list)
 // force evaluations feed no energy read (all but the last step of a timestep() call); the default is 1 (always compute).
 extern "C" void comdSetEnergyNeeded(SimGpu* sim, int on) { sim->needEnergy = on; }
 
+// thread_atom (the BASELINE-named kernel): candidate lists, then the force kernel
+static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int* cells_list, comdStream_t stream)
+{
+   // Measured on MI355X (LJ 80^3): a workgroup of the 3 live waves per cell runs the kernel in 3.94 ms, cap/64 = 4 waves per cell (the
+   // tail wave exits at once) in 4.72 ms, single-wave workgroups in 5.64 ms.
+   // waves per cell: sized to the occupancy the host last saw (+16 atoms of slack), never more than cap/64.  Cells that outgrow the
+   // estimate stay correct (their waves take extra chunks).  COMD_LJ_WAVES=k forces k (tests use 1 to exercise the extra-chunk path).
+   int w = sim->maxAtoms / 64;
+   if (sim->max_atoms_cell > 0 && (sim->max_atoms_cell + 16 + 63) / 64 < w) w = (sim->max_atoms_cell + 16 + 63) / 64;
+   { const char* e = getenv("COMD_LJ_WAVES"); if (e && atoi(e) > 0 && atoi(e) < w) w = atoi(e); }
+   const int wavesPerBlock = w <= 4 ? w : 4;
+   const unsigned nBlocks = w <= 4 ? (unsigned)num_cells : (unsigned)ceilDiv((long)num_cells * w, 4);
+   // candidate lists of the waves (lj_kernels.h): rows sized for 70 % of the fullest stencil the host has seen -- the part of 27 cells
+   // within the cutoff of a whole cell's box is 76 %, of a 64-atom slab of it 61 % -- and a wave whose row is too short walks the stencil.
+   // COMD_LJ_PRUNE=0 switches the lists off (A/B measurements); COMD_LJ_LIST_CAP=n forces rows of n entries (tests: the fallback).
+   const bool pruneEnv = !(getenv("COMD_LJ_PRUNE") && atoi(getenv("COMD_LJ_PRUNE")) == 0);
+   LjPotentialGpu* lj = &sim->lj_pot;
+   if (pruneEnv && !lj->waveCand && lj->packedCap == 0) {
+      const int occ = sim->max_atoms_cell > 0 && sim->max_atoms_cell + 16 < sim->maxAtoms ? sim->max_atoms_cell + 16 : sim->maxAtoms;
+      lj->waveCandWaves = w;
+      lj->waveCandCap = ((int)(0.70 * 27 * occ) + 7) & ~7;
+      { const char* e = getenv("COMD_LJ_LIST_CAP"); if (e && atoi(e) > 0) lj->waveCandCap = (atoi(e) + 7) & ~7; }
+      lj->packedCap = 64 * w < sim->maxAtoms ? 64 * w : sim->maxAtoms;
+      // list entries are 32-bit byte offsets into the packed records
+      if ((double)sim->boxes.nTotalBoxes * lj->packedCap * sizeof(LjPos4) >= 4294967296.0) lj->packedCap = -1;     // no lists for this simulation
+      else {
+         lj->waveCand = dalloc<unsigned>((size_t)sim->boxes.nLocalBoxes * lj->waveCandWaves * lj->waveCandCap, false);
+         lj->waveCandCount = dalloc<int>((size_t)sim->boxes.nLocalBoxes * lj->waveCandWaves * 2, false);
+      }
+   }
+   const bool prune = pruneEnv && lj->waveCand;
+   LjWaveLists wl; memset(&wl, 0, sizeof wl);
+   if (prune) {
+      // the force may be split over two streams (-a 1: interior cells while the halo exchange is in flight, boundary cells after it):
+      // each stream packs the positions it is about to read into its own array
+      const int which = (cells_list && stream != sim->interior_stream) ? 1 : 0;
+      if (!lj->packedR[which]) lj->packedR[which] = dalloc<real_t>((size_t)sim->boxes.nTotalBoxes * lj->packedCap * 4, false);
+      wl.cand = lj->waveCand; wl.pos = (const LjPos4*)lj->packedR[which]; wl.count = (int2*)lj->waveCandCount;
+      wl.candCap = lj->waveCandCap; wl.wavesMax = lj->waveCandWaves; wl.capP = lj->packedCap;
+      wl.rc2Box = a.rc2 * (sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5));
+      wl.grow = sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5);
+      // interior cells never have a halo cell in their stencil, and the halo cells are being filled while they run
+      const int packCells = (cells_list && stream == sim->interior_stream) ? sim->boxes.nLocalBoxes : sim->boxes.nTotalBoxes;
+      hipLaunchKernelGGL(LJ_PackPositions, dim3((unsigned)ceilDiv((long)packCells * lj->packedCap, 256)), dim3(256), 0, S(stream),
+                         a.rx, a.ry, a.rz, a.nAtoms, (LjPos4*)lj->packedR[which], a.cap, lj->packedCap, packCells, a.rc2);
+      hipLaunchKernelGGL(LJ_WaveCandidates, dim3((unsigned)ceilDiv(num_cells, 4)), dim3(256), 0, S(stream), a, wl, w);
+   }
+   ForceTimer timer(sim, S(stream));                     // the force kernel proper (bench.py's roofline line; rocprof must agree with it)
+   if (prune) {
+      if (sim->needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w, wl);
+      else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, true>), dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w, wl);
+   } else {
+      if (sim->needEnergy) hipLaunchKernelGGL((LJ_Force_thread_atom<true, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w, wl);
+      else              hipLaunchKernelGGL((LJ_Force_thread_atom<false, false>), dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w, wl);
+   }
+   LAUNCH_CHECK();
+}
+
 extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream)
 {
    if (num_cells <= 0) return;
    LjArgs a = makeLjArgs(sim, num_cells, cells_list);
+   if (method != THREAD_ATOM_NL && method != WARP_ATOM_NL && method != CTA_CELL) { launchLjThreadAtom(sim, a, num_cells, cells_list, stream); return; }
    ForceTimer timer(sim, S(stream));
    if ((method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat) {
       NeighborListGpu* n = &sim->atoms.neighborList;
@@ -481,18 +541,6 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       else if (n->pairlistBuildId != n->nBuilds) LAUNCH_CTA(1);
       else                                       LAUNCH_CTA(2);
 #undef LAUNCH_CTA
-   } else {
-      // Measured on MI355X (LJ 80^3): a workgroup of the 3 live waves per cell runs the kernel in 3.94 ms, cap/64 = 4 waves per cell (the
-      // tail wave exits at once) in 4.72 ms, single-wave workgroups in 5.64 ms.
-      // waves per cell: sized to the occupancy the host last saw (+16 atoms of slack), never more than cap/64.  Cells that outgrow the
-      // estimate stay correct (their waves take extra chunks).  COMD_LJ_WAVES=k forces k (tests use 1 to exercise the extra-chunk path).
-      int w = sim->maxAtoms / 64;
-      if (sim->max_atoms_cell > 0 && (sim->max_atoms_cell + 16 + 63) / 64 < w) w = (sim->max_atoms_cell + 16 + 63) / 64;
-      { const char* e = getenv("COMD_LJ_WAVES"); if (e && atoi(e) > 0 && atoi(e) < w) w = atoi(e); }
-      const int wavesPerBlock = w <= 4 ? w : 4;
-      const unsigned nBlocks = w <= 4 ? (unsigned)num_cells : (unsigned)ceilDiv((long)num_cells * w, 4);
-      if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_thread_atom<true>, dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w);
-      else              hipLaunchKernelGGL(LJ_Force_thread_atom<false>, dim3(nBlocks), dim3(64 * wavesPerBlock), 0, S(stream), a, w);
    }
    LAUNCH_CHECK();
 }

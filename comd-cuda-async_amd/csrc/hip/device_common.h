@@ -28,12 +28,10 @@ typedef double2 real2;
 // 1/x to round-off.  fp64: v_rcp_f64 is good to ~2^-23 relative, two Newton steps square that twice; fp32: v_rcp_f32 (1 ulp) + one step.
 __device__ __forceinline__ double rcpR(double x)
 {
-   double y = __builtin_amdgcn_rcp(x);
-   double e = __builtin_fma(-x, y, 1.0);
-   y = __builtin_fma(y, e, y);
-   e = __builtin_fma(-x, y, 1.0);
-   y = __builtin_fma(y, e, y);
-   return y;
+   // v_rcp_f64 is good to ~2^-23; with e = 1 - x y0 exactly (fma), 1/x = y0 (1 + e + e^2 + ...): two terms leave e^3 ~ 2^-69
+   const double y = __builtin_amdgcn_rcp(x);
+   const double e = __builtin_fma(-x, y, 1.0);
+   return __builtin_fma(y, __builtin_fma(e, e, e), y);
 }
 __device__ __forceinline__ float rcpR(float x)
 {
@@ -58,6 +56,8 @@ __device__ __forceinline__ float rsqrtR(float x)
    return y * __builtin_fmaf(-h * y, y, 1.5f);
 }
 
+__device__ __forceinline__ double absR(double a) { return __builtin_fabs(a); }
+__device__ __forceinline__ float  absR(float a) { return __builtin_fabsf(a); }
 __device__ __forceinline__ double fmaR(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float  fmaR(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double floorR(double x) { return __builtin_floor(x); }

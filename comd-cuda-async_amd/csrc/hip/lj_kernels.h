@@ -21,22 +21,25 @@ struct LjArgs {
    const int* __restrict__ nbr;        // [nLocal*27], self first
    const int* __restrict__ cells;      // optional cell list
    int nCells, cap;
-   real_t rc2, s6, eShift, eps;
+   real_t rc2, s6, s6x2, eShift, eps;
 };
 
-// One accepted pair.  With u = s6 / r^6:  e_pair = u (u - 1) - eShift,  f_pair = 24 u (2u - 1) / r^2 * d.
-// The constant factors (24 eps on the force, 4 eps * 1/2 on the energy) are applied once per atom by the caller.
+// One accepted pair.  With w = 1 / r^6:  e_pair = s6 w (s6 w - 1) - eShift,  f_pair = 24 s6 w (2 s6 w - 1) / r^2 * d.
+// The constant factors (24 eps s6 on the force, 4 eps * 1/2 on the energy) are applied once per atom by the caller, which leaves
+// q = 1/r^8 and g = 2 s6 w - 1 here: eleven VALU operations after v_rcp_f64.
 // ENERGY = false drops the energy ops: e[] is only consumed by computeEnergy, i.e. by the last step of a timestep() call.
 template <bool ENERGY>
 __device__ __forceinline__ void ljPair(real_t dx, real_t dy, real_t dz, real_t r2, const LjArgs& a,
                                        real_t& fx, real_t& fy, real_t& fz, real_t& e)
 {
    const real_t ir2 = rcpR(r2);
-   const real_t u = a.s6 * ir2 * ir2 * ir2;
-   if (ENERGY) e += fmaR(u, u - R(1.0), -a.eShift);
-   const real_t fr = u * ir2 * fmaR(u, R(2.0), -R(1.0));
+   const real_t t = ir2 * ir2;
+   const real_t w = t * ir2;
+   if (ENERGY) { const real_t u = a.s6 * w; e += fmaR(u, u - R(1.0), -a.eShift); }
+   const real_t fr = (t * t) * fmaR(w, a.s6x2, -R(1.0));
    fx = fmaR(fr, dx, fx); fy = fmaR(fr, dy, fy); fz = fmaR(fr, dz, fz);
 }
+#define LJ_FORCE_SCALE(a) (R(24.0) * (a).eps * (a).s6)
 
 // one neighbour cell against the wave's 64 i atoms; SELF adds the r2 > 0 guard of the own cell
 template <bool SELF, bool ENERGY>
@@ -66,6 +69,190 @@ __device__ __forceinline__ void ljCellLoop(const LjArgs& a, int jBox, real_t xi,
       real_t r2 = dx*dx + dy*dy + dz*dz;
       bool hit = SELF ? (r2 <= a.rc2 && r2 > R(0.0)) : (r2 <= a.rc2);
       if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+   }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Wave candidate lists.  A full wave tests every atom of the 27-cell stencil against its 64 atoms (4000 candidates per atom for
+// 5-sigma LJ Cu), but an atom further than the cutoff from the bounding box of those 64 atoms is a miss for every lane.
+// LJ_WaveCandidates drops them before the force kernel runs: one wave per (cell, 64-slot chunk), 64 stencil atoms per trip (one
+// per lane), point-to-box distance, ballot + mbcnt compaction, global slots appended in stencil order -- the cell's own atoms
+// first, so the order of every lane's sum is that of the plain stencil walk and the forces are bit-identical to it.
+// The lists are rebuilt by every force call (no skin, nothing carried over): a pruning device, not a Verlet list.
+// A list that would not fit its row is marked -1 and the force kernel walks the stencil for that wave.
+// One candidate as the force kernel fetches it: the fourth field is rc^2, the same in every record.  Comparing r^2 against the record's copy
+// costs nothing (a scalar operand either way) and keeps all 32 bytes live, so hipcc fetches a candidate with ONE s_load_dwordx8 instead of
+// an x4 + x2 pair -- the scalar cache is the bottleneck of this path (three s_load_dwordx2 per candidate from the SoA arrays: 5.6 ms).
+struct __attribute__((aligned(16))) LjPos4 { real_t x, y, z, rc2; };
+struct LjWaveLists {
+   unsigned* __restrict__ cand;        // [nLocalCells * wavesMax][candCap] byte offsets of the candidates in pos ((cell * capP + i) * sizeof(LjPos4))
+   const LjPos4* __restrict__ pos;     // [nTotalCells * capP] packed records of slots 0 .. capP-1 of every cell (LJ_PackPositions)
+   int2*     __restrict__ count;       // [nLocalCells * wavesMax] {candidates of the own cell, all candidates}; y < 0: no list
+   int candCap, wavesMax;
+   int capP;                           // slots per cell in pos (<= cap: the waves the lists are laid out for); a stencil with a fuller cell gets no lists
+   real_t rc2Box, grow;                // rc^2 and a factor on the half widths, each with a margin for the rounding of the box distance
+};
+
+// a list entry is the BYTE offset of the candidate in the packed position array (32 bits: base + zero-extended offset is the s_load
+// soffset form, no address arithmetic per candidate)
+__device__ __forceinline__ LjPos4 atByte(const LjPos4* __restrict__ base, unsigned byteOff) { return *(const LjPos4*)((const char*)base + byteOff); }
+
+template <bool SELF, bool ENERGY>
+__device__ __forceinline__ void ljListLoop(const LjArgs& a, const LjPos4* __restrict__ pos, const unsigned* __restrict__ L, int p, int pEnd,
+                                           real_t xi, real_t yi, real_t zi, real_t& fx, real_t& fy, real_t& fz, real_t& e)
+{
+   // the list is wave-uniform: eight offsets per s_load_dwordx8, then one scalar load per candidate
+   for (; p + 8 <= pEnd; p += 8) {
+      unsigned id[8];
+      LjPos4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) id[u] = L[p + u];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = atByte(pos, id[u]);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+         real_t dx = xi - q[u].x, dy = yi - q[u].y, dz = zi - q[u].z;
+         real_t r2 = dx*dx + dy*dy + dz*dz;
+         bool hit = SELF ? (r2 <= q[u].rc2 && r2 > R(0.0)) : (r2 <= q[u].rc2);     // (the record's own copy of rc^2: see LjPos4)
+         if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+      }
+   }
+   for (; p < pEnd; ++p) {
+      const LjPos4 q = atByte(pos, L[p]);
+      real_t dx = xi - q.x, dy = yi - q.y, dz = zi - q.z;
+      real_t r2 = dx*dx + dy*dy + dz*dz;
+      bool hit = SELF ? (r2 <= q.rc2 && r2 > R(0.0)) : (r2 <= q.rc2);
+      if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+   }
+}
+
+// x, y, z of every occupied slot side by side, so that one scalar load fetches a candidate
+__global__ __launch_bounds__(256)
+void LJ_PackPositions(const real_t* __restrict__ rx, const real_t* __restrict__ ry, const real_t* __restrict__ rz, const int* __restrict__ nAtoms,
+                      LjPos4* __restrict__ pos, int cap, int capP, int nCells, real_t rc2)
+{
+   const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int c = (int)(t / capP), i = (int)(t - (long)c * capP);
+   if (c >= nCells || i >= nAtoms[c]) return;
+   const size_t o = (size_t)c * cap + i;
+   LjPos4 v; v.x = rx[o]; v.y = ry[o]; v.z = rz[o]; v.rc2 = rc2;
+   pos[(size_t)c * capP + i] = v;
+}
+
+__device__ __forceinline__ real_t waveMinR(real_t v) { for (int d = 1; d < 64; d <<= 1) v = minR(v, __shfl_xor(v, d)); return v; }
+__device__ __forceinline__ real_t waveMaxR(real_t v) { for (int d = 1; d < 64; d <<= 1) v = maxR(v, __shfl_xor(v, d)); return v; }
+
+__device__ __forceinline__ double uniformR(double v)
+{
+   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(v) & 0xffffffffll));
+   const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(__double_as_longlong(v) >> 32));
+   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ float uniformR(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+
+// One wave per cell builds the lists of all of the cell's waves in one sweep over the stencil (the sweep is L2 traffic: one per list made
+// this kernel bandwidth-bound at 0.39 ms).  Boxes are held as centre + half width: the distance of a point to the box along an axis is
+// max(0, |x - c| - h).
+#define LJ_LIST_CHUNKS 4                      // lists built per sweep (cells of up to 256 atoms need one sweep)
+__global__ __launch_bounds__(256)
+void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
+{
+   const int lane = threadIdx.x & 63;
+   const int ci = uniform(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+   if (ci >= a.nCells) return;
+   const int iBox = uniform(a.cells ? a.cells[ci] : ci);
+   const int ni = uniform(a.nAtoms[iBox]);
+   int nChunks = (ni + 63) >> 6;                            // waves of the force kernel that look for a list: chunk < wavesPerCell, chunk < wavesMax
+   if (nChunks > wavesPerCell) nChunks = wavesPerCell;
+   if (nChunks > w.wavesMax) nChunks = w.wavesMax;
+   if (nChunks <= 0) return;
+   // the stencil's cell ids and occupancies, one per lane, read back with v_readlane (this kernel stores, so hipcc would not use scalar
+   // loads for them, and two dependent vector loads per cell in front of the position loads are two exposed latencies per cell)
+   const int myBox = lane < 27 ? a.nbr[(size_t)iBox * 27 + lane] : 0;
+   const int myCount = lane < 27 ? a.nAtoms[myBox] : 0;
+   if (__ballot(myCount > w.capP) != 0ull) {                // a stencil cell holds atoms the packed array has no room for: walk the stencil
+      if (lane < nChunks) w.count[iBox * w.wavesMax + lane] = make_int2(0, -1);
+      return;
+   }
+
+   for (int c0 = 0; c0 < nChunks; c0 += LJ_LIST_CHUNKS) {
+      real_t cx[LJ_LIST_CHUNKS], cy[LJ_LIST_CHUNKS], cz[LJ_LIST_CHUNKS], hx[LJ_LIST_CHUNKS], hy[LJ_LIST_CHUNKS], hz[LJ_LIST_CHUNKS];
+      int n[LJ_LIST_CHUNKS], nSelf[LJ_LIST_CHUNKS];
+      bool fits[LJ_LIST_CHUNKS];
+#pragma unroll
+      for (int c = 0; c < LJ_LIST_CHUNKS; ++c) {
+         n[c] = 0; nSelf[c] = 0; fits[c] = c0 + c < nChunks;
+         cx[c] = cy[c] = cz[c] = hx[c] = hy[c] = hz[c] = R(0.0);
+         if (c0 + c < nChunks) {
+            const int iSlot = (c0 + c) * 64 + lane;
+            const size_t iOff = (size_t)iBox * a.cap + (iSlot < ni ? iSlot : ni - 1);      // idle lanes shadow the cell's last atom (it is in the last chunk)
+            const real_t xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+            const real_t xlo = waveMinR(xi), xhi = waveMaxR(xi), ylo = waveMinR(yi), yhi = waveMaxR(yi), zlo = waveMinR(zi), zhi = waveMaxR(zi);
+            // half widths rounded up by an ulp-sized factor: the box may only grow
+            cx[c] = uniformR(R(0.5) * (xlo + xhi)); hx[c] = uniformR(R(0.5) * (xhi - xlo) * w.grow);
+            cy[c] = uniformR(R(0.5) * (ylo + yhi)); hy[c] = uniformR(R(0.5) * (yhi - ylo) * w.grow);
+            cz[c] = uniformR(R(0.5) * (zlo + zhi)); hz[c] = uniformR(R(0.5) * (zhi - zlo) * w.grow);
+         }
+      }
+      // cells of up to 256 atoms in one round of four 64-atom trips, loaded one cell ahead of the tests
+      real_t x[4], y[4], z[4], xn[4], yn[4], zn[4];
+      int jBox = __builtin_amdgcn_readlane(myBox, 0), nj = __builtin_amdgcn_readlane(myCount, 0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+         const int j = 64 * t + lane;
+         if (64 * t < nj) { const size_t o = (size_t)jBox * a.cap + (j < nj ? j : 0); xn[t] = a.rx[o]; yn[t] = a.ry[o]; zn[t] = a.rz[o]; }
+      }
+      for (int k = 0; k < 27; ++k) {
+         const int jBoxNow = jBox, njNow = nj;
+#pragma unroll
+         for (int t = 0; t < 4; ++t) { x[t] = xn[t]; y[t] = yn[t]; z[t] = zn[t]; }
+         if (k + 1 < 27) {
+            jBox = __builtin_amdgcn_readlane(myBox, k + 1); nj = __builtin_amdgcn_readlane(myCount, k + 1);
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+               const int j = 64 * t + lane;
+               if (64 * t < nj) { const size_t o = (size_t)jBox * a.cap + (j < nj ? j : 0); xn[t] = a.rx[o]; yn[t] = a.ry[o]; zn[t] = a.rz[o]; }
+            }
+         }
+         const size_t base = (size_t)jBoxNow * a.cap;
+         for (int j0 = 0; j0 < njNow; j0 += 256) {
+            if (j0 > 0) {                                  // cells beyond 256 atoms: the later rounds are loaded on the spot
+#pragma unroll
+               for (int t = 0; t < 4; ++t) {
+                  const int j = j0 + 64 * t + lane;
+                  const size_t o = base + (j < njNow ? j : 0);
+                  x[t] = a.rx[o]; y[t] = a.ry[o]; z[t] = a.rz[o];
+               }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+               const int j = j0 + 64 * t + lane;
+               if (j0 + 64 * t >= njNow) break;
+               const unsigned entry = (unsigned)(((size_t)jBoxNow * w.capP + j) * sizeof(LjPos4));
+#pragma unroll
+               for (int c = 0; c < LJ_LIST_CHUNKS; ++c) {
+                  if (!fits[c]) continue;
+                  const real_t dx = maxR(R(0.0), absR(x[t] - cx[c]) - hx[c]);
+                  const real_t dy = maxR(R(0.0), absR(y[t] - cy[c]) - hy[c]);
+                  const real_t dz = maxR(R(0.0), absR(z[t] - cz[c]) - hz[c]);
+                  const bool keep = j < njNow && dx*dx + dy*dy + dz*dz <= w.rc2Box;
+                  const unsigned long long mask = __ballot(keep);
+                  const int add = __popcll(mask);
+                  if (n[c] + add > w.candCap) { fits[c] = false; continue; }
+                  unsigned* __restrict__ L = w.cand + (size_t)(iBox * w.wavesMax + c0 + c) * w.candCap;
+                  if (keep) L[n[c] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = entry;
+                  n[c] += add;
+               }
+            }
+         }
+         if (k == 0) {
+#pragma unroll
+            for (int c = 0; c < LJ_LIST_CHUNKS; ++c) nSelf[c] = n[c];
+         }
+      }
+#pragma unroll
+      for (int c = 0; c < LJ_LIST_CHUNKS; ++c)
+         if (c0 + c < nChunks && lane == 0) w.count[iBox * w.wavesMax + c0 + c] = fits[c] ? make_int2(nSelf[c], n[c]) : make_int2(0, -1);
    }
 }
 
@@ -107,7 +294,51 @@ __device__ __forceinline__ void ljChunkGeneric(const LjArgs& a, int iBox, int ni
       if (ENERGY) te += bpermuteR(e, src);
    }
    if (lane < m) {
-      const real_t fs = R(24.0) * a.eps;
+      const real_t fs = LJ_FORCE_SCALE(a);
+      a.fx[iOff] = tx * fs; a.fy[iOff] = ty * fs; a.fz[iOff] = tz * fs;
+      if (ENERGY) a.e[iOff] = te * R(2.0) * a.eps;
+   }
+}
+
+// The generic chunk with a candidate list: replica g takes the g-th part of the list (parts of a multiple of four entries, so that a lane
+// fetches four offsets with one 16-byte load), candidates arrive through per-lane loads of the packed records.
+template <bool ENERGY>
+__device__ __forceinline__ void ljChunkListed(const LjArgs& a, const LjPos4* __restrict__ pos, const unsigned* __restrict__ L, int nAll,
+                                              int iBox, int ni, int chunk, int lane)
+{
+   const int m = ni - chunk * 64 < 64 ? ni - chunk * 64 : 64;
+   const int G = 64 / m < 4 ? 64 / m : 4;
+   const int g = lane / m, ai = lane - g * m;
+   const bool valid = g < G;
+   const size_t iOff = (size_t)iBox * a.cap + chunk * 64 + (valid ? ai : 0);
+   const real_t xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
+   real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0);
+   const int len = (((nAll + G - 1) / G) + 3) & ~3;          // entries per replica
+   const int first = valid ? g * len : nAll;
+   const int mine = nAll - first < len ? nAll - first : len;  // may be <= 0
+   const uint4* __restrict__ L4 = reinterpret_cast<const uint4*>(L + (valid ? first : 0));
+   for (int it = 0; it < len; it += 4) {
+      const bool on = it < mine;
+      const uint4 id = on ? L4[it >> 2] : make_uint4(0u, 0u, 0u, 0u);
+      const unsigned ids[4] = { id.x, id.y, id.z, id.w };
+      LjPos4 q[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) q[u] = atByte(pos, it + u < mine ? ids[u] : 0u);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+         const real_t dx = xi - q[u].x, dy = yi - q[u].y, dz = zi - q[u].z;
+         const real_t r2 = dx*dx + dy*dy + dz*dz;
+         if (it + u < mine && r2 <= a.rc2 && r2 > R(0.0)) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+      }
+   }
+   real_t tx = fx, ty = fy, tz = fz, te = e;
+   for (int r = 1; r < G; ++r) {                       // all lanes take part; only lanes < m keep the result
+      const int src = (ai + r * m) & 63;
+      tx += bpermuteR(fx, src); ty += bpermuteR(fy, src); tz += bpermuteR(fz, src);
+      if (ENERGY) te += bpermuteR(e, src);
+   }
+   if (lane < m) {
+      const real_t fs = LJ_FORCE_SCALE(a);
       a.fx[iOff] = tx * fs; a.fy[iOff] = ty * fs; a.fz[iOff] = tz * fs;
       if (ENERGY) a.e[iOff] = te * R(2.0) * a.eps;
    }
@@ -118,9 +349,10 @@ __device__ __forceinline__ void ljChunkGeneric(const LjArgs& a, int iBox, int ni
 // grid: one workgroup of `wavesPerCell` waves per cell, where wavesPerCell = ceil((largest occupancy + slack) / 64) as
 // last seen by the host (SimGpu.max_atoms_cell) -- 3 waves for 5-sigma LJ Cu instead of cap/64 = 4, so no wave is born dead.
 // A cell that outgrew that estimate is still complete: its waves take the extra chunks through the generic path.
-template <bool ENERGY>
+// LISTED: the full waves read the candidates LJ_WaveCandidates left for them instead of walking the 27 cells.
+template <bool ENERGY, bool LISTED>
 __global__ __launch_bounds__(256)
-void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
+void LJ_Force_thread_atom(LjArgs a, int wavesPerCell, LjWaveLists w)
 {
    const int lane = threadIdx.x & 63;
    // one workgroup per cell when wavesPerCell <= 4 (blockDim = 64 * wavesPerCell); otherwise 4-wave workgroups laid flat over (cell, chunk)
@@ -133,8 +365,15 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
    if (chunk * 64 >= ni) return;
    const int m = uniform(ni - chunk * 64 < 64 ? ni - chunk * 64 : 64);     // atoms this wave owns
 
+   int nSelf = 0, nAll = -1;                                                // this wave's candidate list, if it has one
+   if (LISTED && chunk < w.wavesMax) {
+      const int2 c = w.count[iBox * w.wavesMax + chunk];
+      nSelf = uniform(c.x); nAll = uniform(c.y);
+   }
+   const unsigned* __restrict__ L = LISTED ? w.cand + (size_t)(iBox * w.wavesMax + chunk) * w.candCap : nullptr;
    if (m <= 32) {
-      ljChunkGeneric<ENERGY>(a, iBox, ni, chunk, lane);
+      if (LISTED && nAll >= 0) ljChunkListed<ENERGY>(a, w.pos, L, nAll, iBox, ni, chunk, lane);
+      else                     ljChunkGeneric<ENERGY>(a, iBox, ni, chunk, lane);
    } else {
       // full wave: neighbour j is wave-uniform -> positions arrive through the scalar unit
       const int* __restrict__ nb = a.nbr + (size_t)iBox * 27;
@@ -145,10 +384,15 @@ void LJ_Force_thread_atom(LjArgs a, int wavesPerCell)
       real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0);
       // (a software-pipelined variant -- scalar loads of batch b+1 issued before batch b is evaluated, 4 neighbours per batch to fit
       // two batches in SGPRs -- measured 9 % slower: 4.30 vs 3.95 ms; the 8-wide batches below rely on the other waves for latency cover)
-      ljCellLoop<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
-      for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
+      if (LISTED && nAll >= 0) {
+         ljListLoop<true, ENERGY>(a, w.pos, L, 0, nSelf, xi, yi, zi, fx, fy, fz, e);
+         ljListLoop<false, ENERGY>(a, w.pos, L, nSelf, nAll, xi, yi, zi, fx, fy, fz, e);
+      } else {
+         ljCellLoop<true, ENERGY>(a, iBox, xi, yi, zi, fx, fy, fz, e);
+         for (int k = 1; k < 27; ++k) ljCellLoop<false, ENERGY>(a, uniform(nb[k]), xi, yi, zi, fx, fy, fz, e);
+      }
       if (active) {
-         const real_t fs = R(24.0) * a.eps;
+         const real_t fs = LJ_FORCE_SCALE(a);
          a.fx[iOff] = fx * fs; a.fy[iOff] = fy * fs; a.fz[iOff] = fz * fs;
          if (ENERGY) a.e[iOff] = e * R(2.0) * a.eps;          // 4 eps * 1/2 per pair
       }
@@ -289,7 +533,7 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
          else         slabLoop<2, PL, false, ENERGY>(sx, sy, sz, nSlab, a, xi, yi, zi, fx, fy, fz, e, plWords, pl.plCut2, own);
       }
    }
-   const real_t fs = R(24.0) * a.eps;
+   const real_t fs = LJ_FORCE_SCALE(a);
 #pragma unroll
    for (int u = 0; u < 2; ++u)
       if (own[u]) {

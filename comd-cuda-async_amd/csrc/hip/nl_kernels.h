@@ -110,7 +110,7 @@ void LJ_Force_thread_atom_nl(LjArgs a, NlView nl)
       const real_t r2 = dx*dx + dy*dy + dz*dz;
       if (r2 <= a.rc2) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
    }
-   const real_t fs = R(24.0) * a.eps;
+   const real_t fs = LJ_FORCE_SCALE(a);
    a.fx[iSlot] = fx * fs; a.fy[iSlot] = fy * fs; a.fz[iSlot] = fz * fs;
    if (ENERGY) a.e[iSlot] = e * R(2.0) * a.eps;
 }
@@ -359,7 +359,7 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
       }
    }
    if (active) {
-      const real_t fs = R(24.0) * a.eps;
+      const real_t fs = LJ_FORCE_SCALE(a);
       a.fx[iSlot] = fx * fs; a.fy[iSlot] = fy * fs; a.fz[iSlot] = fz * fs;
       if (ENERGY) a.e[iSlot] = e * R(2.0) * a.eps;
    }

@@ -49,7 +49,17 @@ typedef struct InterpolationObjectGpu {
 } InterpolationObjectGpu;
 
 /* gpu_types.h:72-79 */
-typedef struct LjPotentialGpu { real_t cutoff, sigma, epsilon; } LjPotentialGpu;
+typedef struct LjPotentialGpu {
+   real_t cutoff, sigma, epsilon;
+   /* thread_atom: before each force evaluation every full wave (64 consecutive slots of a cell) gets the list of the stencil atoms that lie
+    * within the cutoff of the bounding box of its atoms; the force kernel tests only those.  Allocated by the first thread_atom launch. */
+   unsigned* waveCand;                 /* device [nLocalBoxes * waveCandWaves][waveCandCap] global slots */
+   int*      waveCandCount;            /* device [nLocalBoxes * waveCandWaves][2]: {own-cell candidates, all candidates}; second < 0: no list */
+   int       waveCandCap, waveCandWaves;
+   int       packedCap;                /* slots per cell in packedR (<= maxAtoms) */
+   real_t*   packedR[2];               /* device [nTotalBoxes * packedCap][4]: {x, y, z, cutoff^2} of the occupied slots, refreshed by every thread_atom
+                                        * force call; [1] is used by calls on a stream other than interior_stream when the force is split (-a 1) */
+} LjPotentialGpu;
 
 /* gpu_types.h:60-69: cubic spline in r^2 (-P, `spline` argument of eamForce*Gpu): coefficients {a,b,c,d} per table interval,
  * f(r) = ((a r2 + b) r2 + c) r2 + d; the interval is picked with single-precision arithmetic as in the reference */

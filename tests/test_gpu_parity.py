@@ -93,6 +93,22 @@ def test_lj_cells_larger_than_the_launch_estimate(gpu, orc, monkeypatch):
         assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
 
 
+@pytest.mark.parametrize("env", [{"COMD_LJ_PRUNE": "0"}, {"COMD_LJ_LIST_CAP": "64"}, {"COMD_LJ_LIST_CAP": "2200"}, {}])
+def test_lj_wave_candidate_lists_and_their_fallbacks(gpu, orc, monkeypatch, env):
+    """thread_atom tests only the stencil atoms within the cutoff of each wave's bounding box (LJ_WaveCandidates).  The four legs: lists
+    off (the plain 27-cell walk), rows too short for any wave (every wave falls back to the walk), rows that fit the tail waves' lists but
+    not the full waves' (both paths inside one launch), and the default.  All four must give the oracle's forces."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with gpu.Simulation(_args((12, 10, 11), 0, 0.15, "thread_atom")) as sim:
+        o = orc.Oracle((12, 10, 11), eam=0, delta=0.15, cap=max(sim.max_atoms, 64))
+        sim.step(2)
+        o.step(2)
+        f, fo = sim.gather(2), o.gather(orc.F)
+        assert np.abs(f - fo).max() <= TOL["force_rel_to_max"] * np.abs(fo).max()
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+
+
 @pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("case", ["eam_6_delta", "lj_8_delta"])
 def test_reference_recorded_forces(gpu, case, method):

@@ -144,10 +144,14 @@ def test_lj_thread_atom_keeps_its_scalar_load_stream(tmp_path):
                            "-I" + os.path.dirname(src), "-S", "--cuda-device-only", "-o", str(out), src], capture_output=True, text=True)
     assert proc.returncode == 0, proc.stderr[-2000:]
     text = out.read_text()
-    kernels = re.findall(r"^(_Z20LJ_Force_thread_atomILb[01]EEv6LjArgsi):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
-    assert len(kernels) == 2
-    for name, body in kernels:
-        assert body.count("s_load_dwordx16") >= 3, name
+    kernels = re.findall(r"^(_Z20LJ_Force_thread_atomILb[01]ELb([01])EEv6LjArgsi11LjWaveLists):[^\n]*\n(.*?)s_endpgm", text, flags=re.S | re.M)
+    assert len(kernels) == 4
+    for name, listed, body in kernels:
+        assert body.count("s_load_dwordx16") >= 3, name             # the stencil walk (the only path when LISTED = 0, the fallback otherwise)
+        if listed == "1":
+            # candidate lists: eight byte offsets per s_load_dwordx8, then one s_load_dwordx2 per coordinate with the offset in an SGPR
+            # (no 64-bit address arithmetic per candidate) -- two unrolled loops of 8 candidates x 3 coordinates
+            assert len(re.findall(r"s_load_dwordx2 s\[\d+:\d+\], s\[\d+:\d+\], s\d+", body)) >= 48, name
 
 
 @pytest.mark.parametrize("extra,pot_name", [((), "Cu_u6.eam"), (("-t", "setfl", "-p", "Cu01.eam.alloy"), "Cu01.eam.alloy")])
