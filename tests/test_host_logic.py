@@ -149,9 +149,9 @@ def test_lj_thread_atom_keeps_its_scalar_load_stream(tmp_path):
     for name, listed, body in kernels:
         assert body.count("s_load_dwordx16") >= 3, name             # the stencil walk (the only path when LISTED = 0, the fallback otherwise)
         if listed == "1":
-            # candidate lists: eight byte offsets per s_load_dwordx8, then one s_load_dwordx2 per coordinate with the offset in an SGPR
-            # (no 64-bit address arithmetic per candidate) -- two unrolled loops of 8 candidates x 3 coordinates
-            assert len(re.findall(r"s_load_dwordx2 s\[\d+:\d+\], s\[\d+:\d+\], s\d+", body)) >= 48, name
+            # candidate lists: eight byte offsets per s_load_dwordx8, then ONE s_load_dwordx8 per candidate record with the offset in an
+            # SGPR (no 64-bit address arithmetic, no x4 + x2 split) -- two unrolled loops (own cell, other cells) of 8 candidates
+            assert len(re.findall(r"s_load_dwordx8 s\[\d+:\d+\], s\[\d+:\d+\], s\d+", body)) >= 16, name
 
 
 @pytest.mark.parametrize("extra,pot_name", [((), "Cu_u6.eam"), (("-t", "setfl", "-p", "Cu01.eam.alloy"), "Cu01.eam.alloy")])
