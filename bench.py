@@ -37,6 +37,9 @@ GRIDS = {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}
 # LJ 5 sigma: ~4000 candidates x (3 sub + mul + 2 fma = 8 FLOP) + ~550 pairs x ~25 FLOP; EAM: 2 passes x (~283 x 8 + ~42 x ~70).
 FP64_VECTOR_PEAK_TFLOPS = 78.6
 FORCE_FLOP = {"lj": 4000 * 8 + 550 * 25, "eam": 2 * (283 * 8 + 42 * 70)}
+# LJ thread_atom tests only the candidates its per-wave lists keep (within the cutoff of the wave's bounding box): ~2350 of the 4000
+# (SQ_INSTS_SMEM of the force kernel, profiles/r02_pmc_summary.json) -- the FLOP it executes usefully, not the stencil's
+FORCE_FLOP_LISTED = {"lj": 2350 * 8 + 550 * 25}
 # Verlet lists (skin 10 %): ~732 (LJ) / ~57 (EAM) listed neighbours take the place of the stencil candidates
 FORCE_FLOP_NL = {"lj": 732 * 8 + 550 * 25, "eam": 2 * (57 * 8 + 42 * 70)}
 KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs", ("lj", "cta_cell_pairlist"): "LJ_Force_cta_cell",
@@ -247,6 +250,8 @@ def main():
         value = n_global * a.steps / elapsed
         force_per_step_ms = force_ms / a.steps                 # all force launches of one step on rank 0
         flop = (FORCE_FLOP_NL if method.endswith("_nl") else FORCE_FLOP)[a.pot]
+        if a.pot == "lj" and method == "thread_atom" and os.environ.get("COMD_LJ_PRUNE", "1") != "0":
+            flop = FORCE_FLOP_LISTED["lj"]
         achieved = FORCE_BYTES[a.pot] * n_local / (force_per_step_ms * 1e-3) / 1e9 if force_ms > 0 else None
         out = {
             "metric": "atom_updates_per_sec", "value": value, "unit": "atom-updates/s",
@@ -268,7 +273,7 @@ def main():
                          ("fp64_vector" if a.precision == "double" else "fp32_vector"): {"achieved_TFLOPs": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 if force_ms > 0 else None,
                                          "peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "flop_per_atom": flop,
                                          "frac": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if force_ms > 0 else None},
-                         "note": "fp64 ALU-bound stencil: ~4000 (LJ) / ~283 (EAM) candidate pairs per atom against 56 / 176 algorithmic bytes (SURVEY.md 8d)"},
+                         "note": "fp64 ALU-bound stencil: ~4000 (LJ; ~2350 after the per-wave box pruning of thread_atom) / ~283 (EAM) candidate pairs per atom against 56 / 176 algorithmic bytes (SURVEY.md 8d)"},
         }
         if method == "thread_atom_nl":
             out["config"]["neighbor_list_builds_timed"] = m["nl_builds"]

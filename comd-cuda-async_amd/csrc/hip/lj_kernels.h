@@ -98,32 +98,42 @@ struct LjWaveLists {
 __device__ __forceinline__ LjPos4 atByte(const LjPos4* __restrict__ base, unsigned byteOff) { return *(const LjPos4*)((const char*)base + byteOff); }
 
 template <bool SELF, bool ENERGY>
+__device__ __forceinline__ void ljListTest(const LjArgs& a, const LjPos4& q, real_t xi, real_t yi, real_t zi, real_t& fx, real_t& fy, real_t& fz, real_t& e)
+{
+   real_t dx = xi - q.x, dy = yi - q.y, dz = zi - q.z;
+   real_t r2 = dx*dx + dy*dy + dz*dz;
+   bool hit = SELF ? (r2 <= q.rc2 && r2 > R(0.0)) : (r2 <= q.rc2);        // (the record's own copy of rc^2: see LjPos4)
+   if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+}
+
+template <bool SELF, bool ENERGY>
 __device__ __forceinline__ void ljListLoop(const LjArgs& a, const LjPos4* __restrict__ pos, const unsigned* __restrict__ L, int p, int pEnd,
                                            real_t xi, real_t yi, real_t zi, real_t& fx, real_t& fy, real_t& fz, real_t& e)
 {
-   // the list is wave-uniform: eight offsets per s_load_dwordx8, then one scalar load per candidate
-   for (; p + 8 <= pEnd; p += 8) {
+   // The list is wave-uniform: eight offsets per s_load_dwordx8, one s_load_dwordx8 per candidate record.  The offsets of batch b + 1 are
+   // fetched together with the records of batch b, so a batch costs one exposed scalar-load latency, not two dependent ones.
+   // (Records one half batch ahead as well -- two sets of four in flight -- needs 25 SGPR spill reloads per batch: not kept.)
+   const int n8 = (pEnd - p) >> 3;
+   if (n8 > 0) {
+      const int last = p + 8 * (n8 - 1);                      // the prefetch past the last batch re-reads it (valid offsets, unused)
       unsigned id[8];
-      LjPos4 q[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) id[u] = L[p + u];
+      for (int b = 0; b < n8; ++b, p += 8) {
+         LjPos4 q[8];
+         unsigned idn[8];
+         const int pn = p + 8 < last ? p + 8 : last;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) q[u] = atByte(pos, id[u]);
+         for (int u = 0; u < 8; ++u) q[u] = atByte(pos, id[u]);
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-         real_t dx = xi - q[u].x, dy = yi - q[u].y, dz = zi - q[u].z;
-         real_t r2 = dx*dx + dy*dy + dz*dz;
-         bool hit = SELF ? (r2 <= q[u].rc2 && r2 > R(0.0)) : (r2 <= q[u].rc2);     // (the record's own copy of rc^2: see LjPos4)
-         if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
+         for (int u = 0; u < 8; ++u) idn[u] = L[pn + u];
+#pragma unroll
+         for (int u = 0; u < 8; ++u) ljListTest<SELF, ENERGY>(a, q[u], xi, yi, zi, fx, fy, fz, e);
+#pragma unroll
+         for (int u = 0; u < 8; ++u) id[u] = idn[u];
       }
    }
-   for (; p < pEnd; ++p) {
-      const LjPos4 q = atByte(pos, L[p]);
-      real_t dx = xi - q.x, dy = yi - q.y, dz = zi - q.z;
-      real_t r2 = dx*dx + dy*dy + dz*dz;
-      bool hit = SELF ? (r2 <= q.rc2 && r2 > R(0.0)) : (r2 <= q.rc2);
-      if (hit) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
-   }
+   for (; p < pEnd; ++p) ljListTest<SELF, ENERGY>(a, atByte(pos, L[p]), xi, yi, zi, fx, fy, fz, e);
 }
 
 // x, y, z of every occupied slot side by side, so that one scalar load fetches a candidate

@@ -65,7 +65,7 @@ for d in sorted(glob.glob(O+"/pmc_*")):
     acc=collections.defaultdict(lambda: collections.defaultdict(float)); cnt=collections.defaultdict(collections.Counter)
     for r in csv.DictReader(open(f[0])):
         k=r["Kernel_Name"].split("(")[0].replace("void ","")
-        if "Force" in k or "Build" in k:
+        if "Force" in k or "Build" in k or "Candidates" in k or "Pack" in k:
             acc[k][r["Counter_Name"]]+=float(r["Counter_Value"]); cnt[k][r["Counter_Name"]]+=1
     out[os.path.basename(d)]={k:{c:{"per_launch":acc[k][c]/cnt[k][c],"launches":cnt[k][c]} for c in acc[k]} for k in acc}
     # raw CSVs are large: keep the summary only
