@@ -448,11 +448,17 @@ static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int*
    const bool pruneEnv = !(getenv("COMD_LJ_PRUNE") && atoi(getenv("COMD_LJ_PRUNE")) == 0);
    LjPotentialGpu* lj = &sim->lj_pot;
    if (pruneEnv && !lj->waveCand && lj->packedCap == 0) {
-      const int occ = sim->max_atoms_cell > 0 && sim->max_atoms_cell + 16 < sim->maxAtoms ? sim->max_atoms_cell + 16 : sim->maxAtoms;
+      // the fullest cell right now (one blocking read, once per simulation; SimGpu.max_atoms_cell may not have been filled in yet)
+      std::vector<int> counts((size_t)sim->boxes.nTotalBoxes);
+      HIP_CHECK(hipMemcpyAsync(counts.data(), sim->boxes.nAtoms, counts.size() * sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+      HIP_CHECK(hipStreamSynchronize(S(stream)));
+      int fullest = sim->max_atoms_cell;
+      for (int c : counts) if (c > fullest) fullest = c;
+      const int occ = fullest + 16 < sim->maxAtoms ? fullest + 16 : sim->maxAtoms;
       lj->waveCandWaves = w;
       lj->waveCandCap = ((int)(0.70 * 27 * occ) + 7) & ~7;
       { const char* e = getenv("COMD_LJ_LIST_CAP"); if (e && atoi(e) > 0) lj->waveCandCap = (atoi(e) + 7) & ~7; }
-      lj->packedCap = 64 * w < sim->maxAtoms ? 64 * w : sim->maxAtoms;
+      lj->packedCap = ((occ + 7) & ~7) < sim->maxAtoms ? ((occ + 7) & ~7) : sim->maxAtoms;     // a stencil with a fuller cell falls back to the walk
       // list entries are 32-bit byte offsets into the packed records
       if ((double)sim->boxes.nTotalBoxes * lj->packedCap * sizeof(LjPos4) >= 4294967296.0) lj->packedCap = -1;     // no lists for this simulation
       else {

@@ -56,7 +56,7 @@ typedef struct LjPotentialGpu {
    unsigned* waveCand;                 /* device [nLocalBoxes * waveCandWaves][waveCandCap] global slots */
    int*      waveCandCount;            /* device [nLocalBoxes * waveCandWaves][2]: {own-cell candidates, all candidates}; second < 0: no list */
    int       waveCandCap, waveCandWaves;
-   int       packedCap;                /* slots per cell in packedR (<= maxAtoms) */
+   int       packedCap;                /* slots per cell in packedR: the fullest cell seen at allocation + 16, at most maxAtoms; -1: no lists (the array would pass 4 GiB) */
    real_t*   packedR[2];               /* device [nTotalBoxes * packedCap][4]: {x, y, z, cutoff^2} of the occupied slots, refreshed by every thread_atom
                                         * force call; [1] is used by calls on a stream other than interior_stream when the force is split (-a 1) */
 } LjPotentialGpu;
