@@ -1,10 +1,14 @@
-# Round-2 evidence, collected in ONE gpurun call on the MI355X box:  gpurun --timeout 1190 -- 'bash profiles/r02_collect.sh'
+# Round-2 evidence, collected in TWO gpurun calls on the MI355X box (the GPU suite alone takes five minutes):
+#   gpurun --timeout 1190 -- 'bash profiles/r02_collect.sh 1'     tests, smoke, benches, comd-hip stdouts, loopback legs
+#   gpurun --timeout 1190 -- 'bash profiles/r02_collect.sh 2'     rocprofv3 stats + PMC passes, 256^3
 # then, here:  python3 profiles/r02_summarize.py   (copies what is to be tracked into profiles/ and writes r02_summary.md)
 set -e
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/r02final
-rm -rf $O; mkdir -p $O
+PHASE=${1:-1}
+mkdir -p $O
 cd $R
+if [ "$PHASE" = "1" ]; then
 timeout -k 10 700 python -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
 tail -2 $O/gpu_tests.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 || { tail -20 $O/smoke.log; exit 1; }
@@ -30,6 +34,8 @@ COMD_LOOPBACK_TRANSPORT=1 COMD_HALO_HANDSHAKE=1 python bench.py --pot eam --no-v
 python bench.py --no-variants --no-cpu-baseline > $O/plain_lj.json 2>/dev/null
 python bench.py --pot eam --no-variants --no-cpu-baseline > $O/plain_eam.json 2>/dev/null
 echo "loopback benches done"
+exit 0
+fi
 cd /tmp && export TMPDIR=/tmp
 for c in "lj thread_atom" "lj thread_atom_nl" "lj cta_cell" "eam cta_cell" "eam thread_atom_nl" "eam thread_atom"; do
   set -- $c
