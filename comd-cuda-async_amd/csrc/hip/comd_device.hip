@@ -640,10 +640,10 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       // a stencil of 27 cells at the perfect-lattice density + 30 % (thermal crowding, cells fuller than the mean), whole staging rounds of 64
       const double cellVol = 1.0 / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);
       const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
-      int stencil = (int)(27.0 * cellVol * 4.0 / (lat * lat * lat) * 1.30) + 16;
-      stencil = ((stencil + 63) / 64) * 64;
+      const double perStencil = 27.0 * cellVol * 4.0 / (lat * lat * lat);
+      int stencil = (((int)(perStencil * 1.30) + 16 + 7) / 8) * 8;
       if (stencil < 128) stencil = 128;
-      if (stencil > 27 * sim->maxAtoms) stencil = ((27 * sim->maxAtoms + 63) / 64) * 64;
+      if (stencil > 27 * sim->maxAtoms) stencil = ((27 * sim->maxAtoms + 7) / 8) * 8;
       if (stencil > 1024) stencil = 1024;                    // beyond that a cell takes the thread-per-atom form inside the same kernel
       // rows per atom: the cutoff sphere at that density + 50 %, a multiple of 8
       const double rc = sim->eam_pot.cutoff;
@@ -652,13 +652,31 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       // 4 waves per workgroup, one per SIMD (5 or 6 land unevenly on the four SIMDs of a CU: measured 3.4-3.7 ms against 2.6 at 80^3)
       int waves = 4;
       { const char* e = getenv("COMD_EAM_CTA_WAVES"); if (e && atoi(e) >= 1 && atoi(e) <= 8) waves = atoi(e); }
-      if (!sim->eam_pot.pairRows || sim->eam_pot.pairRowLen != rows) {        // first cta_cell launch: rows pass 1 leaves for pass 3
-         if (sim->eam_pot.pairRows) { HIP_CHECK(hipFree(sim->eam_pot.pairRows)); HIP_CHECK(hipFree(sim->eam_pot.pairRowCount)); }
+      if (rows > 256) rows = 256;                            // the hand-over holds 16 lanes x 8 trips x 2 numbers per atom
+      if (!sim->eam_pot.pairRows) {                          // first cta_cell launch: rows pass 1 leaves for pass 3
          const size_t slotsLocal = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
-         sim->eam_pot.pairRows = dalloc<unsigned short>(slotsLocal * rows, false);
+         sim->eam_pot.pairRows = dalloc<unsigned>(slotsLocal * EAM_ROW_WORDS, false);
          sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal);
          sim->eam_pot.pairRowLen = rows;
       }
+      // The LDS slice decides how many workgroups share a CU (gfx950 hands the LDS out in 1280-byte granules, 160 KB per CU), and these kernels
+      // live on latency hiding: at 80^3 a slice of 384 records leaves room for two workgroups per CU in either pass, one of 376 for three
+      // (measured: pass 1 1.43 -> 1.08 ms).  Shrink the slice, down to the density + 20 %, when that buys a workgroup in pass 1 or pass 3;
+      // both passes must use the same size (a cell either has rows or takes the thread-per-atom form, in both).
+      {
+         auto perCu = [&](int step, int st) {
+            const size_t b = eamCtaCellLdsBytes(step, a.rho.n, a.phi.n, tablesInLds, sameGrid, st, rows, waves);
+            return b > 160 * 1024 ? 0 : (int)(160 * 1024 / (((b + 1279) / 1280) * 1280));
+         };
+         const int lo = (((int)(perStencil * 1.20) + 16 + 7) / 8) * 8;
+         int best = stencil, bestScore = perCu(1, stencil) + perCu(3, stencil);
+         for (int st = stencil - 8; st >= lo && st >= 128; st -= 8) {
+            const int score = perCu(1, st) + perCu(3, st);
+            if (score > bestScore) { bestScore = score; best = st; }
+         }
+         stencil = best;
+      }
+      { const char* e = getenv("COMD_EAM_STENCIL"); if (e && atoi(e) >= 64) stencil = (atoi(e) + 7) / 8 * 8; }      // experiments: LDS slice size
       const size_t lds = eamCtaCellLdsBytes(STEP, a.rho.n, a.phi.n, tablesInLds, sameGrid, stencil, rows, waves);
       if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
       const int grid = ceilDiv(num_cells, waves * 8);        // each wave walks ~8 consecutive cells

@@ -729,17 +729,21 @@ static inline size_t eamNlLdsBytes(int step, int nRho, int nPhi, bool sameGrid, 
 //   pipe  : while cell c is built and evaluated out of the LDS, the records of c+1 are in flight into registers and the
 //           description of c+2 (two dependent reads) is on its way.
 // No cross-lane traffic beyond the quad, no queue shared by 64 lanes, and per lane long runs of independent work.
+#define EAM_ROW_WORDS 128                  // hand-over pass 1 -> pass 3: per atom [16 lanes][8 trips] words of two 16-bit record numbers
 __host__ __device__ static inline size_t eamCtaWaveBytes(int rec, int stencilAtoms, int rows)
 {
-   // records (+ F' in pass 3), [32] offsets + [32] cells, [16 atoms][rows] 16-bit record numbers, [16] row lengths
-   return ((size_t)rec * stencilAtoms * sizeof(real_t) + 256 + (size_t)16 * rows * 2 + 64 + 15) & ~(size_t)15;
+   // records (+ F' in pass 3), [32] offsets + [32] cells; pass 1 (rows > 0) adds [16 atoms][rows] 16-bit record numbers and [16] row lengths
+   return ((size_t)rec * stencilAtoms * sizeof(real_t) + 256 + (rows > 0 ? (size_t)16 * rows * 2 + 64 : 0) + 15) & ~(size_t)15;
 }
 
 template <int STEP, bool LDS_TABLES, bool SPLINE>
 __global__ __launch_bounds__(512)
-void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* __restrict__ rowsG, unsigned short* __restrict__ rowCountG,
+void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned* __restrict__ rowsG, unsigned short* __restrict__ rowCountG,
                         int fuseEmbed, int* __restrict__ status)
 {
+   // atoms per round: a lane's share of a row is at most 8 trips x 2 = 16 entries, so an atom needs ceil(rows / 16) lanes
+   // (rows <= 64, funcfl Cu: 4 lanes, 16 atoms per round; Mishin's longer cutoff, rows 88: 6 lanes, 10 atoms per round)
+   const int roundAtoms = 64 / ((rows + 15) / 16) < 16 ? 64 / ((rows + 15) / 16) : 16;
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int REC = 3;                                    // doubles per staged atom: x, y, z (24-byte stride: conflict-free wave-wide reads);
    constexpr int RECD = (STEP == 3) ? 1 : 0;                 // pass 3 keeps F' of the staged atoms in an array of its own
@@ -762,12 +766,12 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
    const TableView rhoT = makeTable(a.rho, LDS_TABLES ? sRho : a.rho.values), phiT = makeTable(a.phi, LDS_TABLES ? sPhi : a.phi.values);
 
    const int wave = uniform(threadIdx.x >> 6), lane = threadIdx.x & 63;
-   real_t* __restrict__ sp = (real_t*)(ldsRaw + eamTableBytesAligned(tableDoubles) + (size_t)wave * eamCtaWaveBytes(REC + RECD, stencilAtoms, rows));
+   real_t* __restrict__ sp = (real_t*)(ldsRaw + eamTableBytesAligned(tableDoubles) + (size_t)wave * eamCtaWaveBytes(REC + RECD, stencilAtoms, STEP == 1 ? rows : 0));
    real_t* __restrict__ sd = sp + REC * stencilAtoms;        // [stencilAtoms] F' (pass 3)
    int* sOff = (int*)(sp + (REC + RECD) * stencilAtoms);     // [32]: exclusive record offsets of the 27 cells, [27] = total
    int* sBox = sOff + 32;                                    // [32]
-   unsigned short* sHit = (unsigned short*)(sBox + 32);
-   int* sCnt = (int*)(sHit + 16 * rows);                     // [16] neighbours of the round's atoms
+   unsigned short* sHit = (unsigned short*)(sBox + 32);      // pass 1 only: [16][rows] rows under construction
+   int* sCnt = (int*)(sHit + 16 * rows);                     // pass 1 only: [16] neighbours of the round's atoms
 
    // cells are dealt to waves in contiguous runs so that neighbouring cells (shared stencil lines) meet in one L2
    const int nWaves = gridDim.x * wavesPerBlock;
@@ -783,21 +787,24 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
    if (ciBegin + 1 < ciEnd) { const int c = cellOf(ciBegin + 1); boxB = lane < 27 ? a.nbr[(size_t)c * 27 + lane] : 0; cntB = lane < 27 ? a.nAtoms[boxB] : 0; }
 
    real_t vx[SR], vy[SR], vz[SR], vd[SR];
-   constexpr int RJ = 4;                                     // 16-byte row chunks a lane keeps in flight (pass 3): 16 rows of up to 128 entries
-   uint4 rowReg[RJ];
+   // pass 3: the lane's own share of its atom's row, as pass 1 left it -- eight words, one per trip of the evaluation loop, each the two
+   // record numbers of that trip -- and the row length; fetched a cell ahead (two 16-byte loads per lane) and kept in registers: no row
+   // table in the LDS, which is what lets a third workgroup share the CU in pass 3
+   uint4 rowLo = make_uint4(0u, 0u, 0u, 0u), rowHi = rowLo;
    int rowCnt = 0;
-   const int cpr = rows >> 3;                                // 16-byte chunks per row
    int totalL = 0, niL = 0, iBoxL = 0;
-   // pass 3: the rows pass 1 left for the atoms of round i0 of cell iBox, 16 bytes per lane and chunk
    auto fetchRows = [&](int iBox, int ni, int i0) {
-#pragma unroll
-      for (int j = 0; j < RJ; ++j) {
-         const int c = lane + 64 * j;
-         const int atom = c / cpr, part = c - atom * cpr;
-         rowReg[j] = make_uint4(0u, 0u, 0u, 0u);
-         if (atom < 16 && i0 + atom < ni) rowReg[j] = *reinterpret_cast<const uint4*>(rowsG + ((size_t)iBox * a.cap + i0 + atom) * rows + part * 8);
+      const int nRound = ni - i0 < roundAtoms ? ni - i0 : roundAtoms;
+      int L = 64 / (nRound > 0 ? nRound : 1); if (L > 16) L = 16;
+      const int ia = (lane * ((65536 + L - 1) / L)) >> 16;
+      const int q = lane - ia * L;
+      rowLo = make_uint4(0u, 0u, 0u, 0u); rowHi = rowLo; rowCnt = 0;
+      if (ia < nRound) {
+         const size_t slot = (size_t)iBox * a.cap + i0 + ia;
+         const uint4* __restrict__ w = reinterpret_cast<const uint4*>(rowsG + slot * EAM_ROW_WORDS + q * 8);
+         rowLo = w[0]; rowHi = w[1];
+         rowCnt = rowCountG[slot];
       }
-      rowCnt = (lane < 16 && i0 + lane < ni) ? rowCountG[(size_t)iBox * a.cap + i0 + lane] : 0;      // lane = atom of the round
    };
    auto issueLoads = [&]() {
       {
@@ -828,14 +835,8 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
       // (a) the loads of cell ci have been issued: land them in the LDS
       const int total = totalL, ni = niL, iBox = iBoxL;
       const bool fits = total <= stencilAtoms;
-      if (STEP == 3 && fits) {                               // rows of the first 16 atoms (prefetched with the records)
-#pragma unroll
-         for (int j = 0; j < RJ; ++j) {
-            const int c = lane + 64 * j;
-            if (c < 16 * cpr) *reinterpret_cast<uint4*>(sHit + c * 8) = rowReg[j];      // chunk c = atom (c / cpr), part (c % cpr): rows are contiguous
-         }
-         if (lane < 16) sCnt[lane] = rowCnt;
-      }
+      uint4 wLo = rowLo, wHi = rowHi;                        // pass 3: rows of the first 16 atoms (prefetched with the records)
+      int nMine = rowCnt;
       if (fits) {
 #pragma unroll
          for (int g = 0; g < SR; ++g) {
@@ -870,11 +871,11 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
          continue;
       }
 
-      // (c) 16 atoms per round: build their neighbour rows in the LDS, then evaluate them
-      for (int i0 = 0; i0 < ni; i0 += 16) {
+      // (c) up to 16 atoms per round: build their neighbour rows in the LDS, then evaluate them
+      for (int i0 = 0; i0 < ni; i0 += roundAtoms) {
          // LANES PER ATOM: as many as the round's atoms leave room for (FCC Cu at 80^3: cells of 9 atoms -> 7 lanes each, 6 -> 10, 13 or 14 -> 4),
          // so a sparsely filled cell does not idle two lanes out of five; lane = L * atom + q, lane q takes rows q, q + L, ...
-         const int nRound = ni - i0 < 16 ? ni - i0 : 16;
+         const int nRound = ni - i0 < roundAtoms ? ni - i0 : roundAtoms;
          int L = 64 / nRound; if (L > 16) L = 16;
          const int ia = (lane * ((65536 + L - 1) / L)) >> 16;          // lane / L (exact for lane < 64)
          const int q = lane - ia * L;
@@ -889,16 +890,13 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
          if (STEP == 3 && have && q == 0) { f0x = a.fx[io]; f0y = a.fy[io]; f0z = a.fz[io]; }
          unsigned short* __restrict__ myRow = sHit + (have ? ia : 0) * rows;
          if (STEP == 3) {
-            // pass 3: the rows pass 1 left behind (same staging order: cells and occupancies do not change inside a force evaluation)
-            if (i0 != 0) {                                           // cells of more than 16 atoms: later rounds fetch their rows here (rowReg holds the next cell's)
-               for (int c = lane; c < 16 * cpr; c += 64) {
-                  const int atom = c / cpr, part = c - atom * cpr;
-                  uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                  if (i0 + atom < ni) v = *reinterpret_cast<const uint4*>(rowsG + ((size_t)iBox * a.cap + i0 + atom) * rows + part * 8);
-                  *reinterpret_cast<uint4*>(sHit + c * 8) = v;
-               }
-               if (lane < 16) sCnt[lane] = i0 + lane < ni ? rowCountG[(size_t)iBox * a.cap + i0 + lane] : 0;
-               __builtin_amdgcn_wave_barrier();
+            // pass 3: the rows pass 1 left behind (same staging order: cells and occupancies do not change inside a force evaluation);
+            // cells of more than 16 atoms fetch the later rounds' here (rowLo/rowHi hold the next cell's by now)
+            if (i0 != 0) {
+               const uint4 keepLo = rowLo, keepHi = rowHi; const int keepCnt = rowCnt;
+               fetchRows(iBox, ni, i0);
+               wLo = rowLo; wHi = rowHi; nMine = rowCnt;
+               rowLo = keepLo; rowHi = keepHi; rowCnt = keepCnt;
             }
          } else {
             // build: two atoms at a time, all 64 lanes on 64 staged records per trip (one read of each record serves both distance
@@ -932,22 +930,16 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
             }
             __builtin_amdgcn_wave_barrier();
          }
-         int n = have ? sCnt[ia] : 0;                        // in-cutoff neighbours of atom i (the same in its L lanes)
+         int n = have ? (STEP == 1 ? sCnt[ia] : nMine) : 0;   // in-cutoff neighbours of atom i (the same in its L lanes)
          if (n > rows) { over = true; n = rows; }
          __builtin_amdgcn_wave_barrier();
-         if (STEP == 1) {                                    // leave the rows for pass 3: 16 bytes per lane and chunk, rows contiguous
-            for (int c = lane; c < 16 * cpr; c += 64) {
-               const int atom = c / cpr, part = c - atom * cpr;
-               if (i0 + atom < ni) *reinterpret_cast<uint4*>(rowsG + ((size_t)iBox * a.cap + i0 + atom) * rows + part * 8) = *reinterpret_cast<const uint4*>(sHit + c * 8);
-            }
-            if (lane < nRound) rowCountG[(size_t)iBox * a.cap + i0 + lane] = (unsigned short)(sCnt[lane] < rows ? sCnt[lane] : rows);
-         }
+         if (STEP == 1 && lane < nRound) rowCountG[(size_t)iBox * a.cap + i0 + lane] = (unsigned short)(sCnt[lane] < rows ? sCnt[lane] : rows);
+         unsigned* __restrict__ myWords = rowsG + ((size_t)iBox * a.cap + ii) * EAM_ROW_WORDS + q * 8;      // pass 1 writes, trip by trip
+         const unsigned wReg[8] = { wLo.x, wLo.y, wLo.z, wLo.w, wHi.x, wHi.y, wHi.z, wHi.w };
 
          real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0);
          // two pairs per trip, branch-free (a missing second pair is evaluated at r = cutoff and weighted 0)
-         for (int k0 = q; k0 < n; k0 += 2 * L) {             // this lane's rows: q, q + L, q + 2L, ... < n
-            const bool h1 = k0 + L < n;
-            const int j0 = myRow[k0], j1 = h1 ? myRow[k0 + L] : ii;
+         auto evalTrip = [&](const int j0, const int j1, const bool h1) {
             const real_t* r0 = sp + REC * j0; const real_t* r1 = sp + REC * j1;
             const real_t dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
             const real_t dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
@@ -982,6 +974,25 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned short* _
             }
             fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
             fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
+         };
+         // this lane's rows: q, q + L, q + 2L, ... < n, two per trip (rows <= 64 and L >= 4: at most 8 trips)
+         if (STEP == 1) {
+            int trip = 0;
+            for (int k0 = q; k0 < n; k0 += 2 * L, ++trip) {
+               const bool h1 = k0 + L < n;
+               const int j0 = myRow[k0], j1 = h1 ? myRow[k0 + L] : ii;
+               myWords[trip] = (unsigned)j0 | ((unsigned)j1 << 16);         // pass 3 reads its rows back lane by lane, trip by trip
+               evalTrip(j0, j1, h1);
+            }
+         } else {
+#pragma unroll
+            for (int trip = 0; trip < 8; ++trip) {           // (unrolled: the words sit in registers)
+               const int k0 = q + 2 * L * trip;
+               if (k0 < n) {
+                  const bool h1 = k0 + L < n;
+                  evalTrip((int)(wReg[trip] & 0xffffu), h1 ? (int)(wReg[trip] >> 16) : ii, h1);
+               }
+            }
          }
          // the L lanes of an atom are consecutive: a shift-down tree adds them into the first (quad-permute DPP when L is 4)
          if (L == 4) {
@@ -1019,5 +1030,5 @@ static inline size_t eamCtaCellLdsBytes(int step, int nRho, int nPhi, bool ldsTa
    const int rec = step == 3 ? 4 : 3;
    size_t tableWords = 0;
    if (ldsTables) tableWords = step == 1 ? (size_t)2 * (nRho + 3) + (sameGrid ? 0 : (nPhi + 3 - (nRho + 3))) : (size_t)(nRho + 3);
-   return eamTableBytesAligned(tableWords) + (size_t)wavesPerBlock * eamCtaWaveBytes(rec, stencilAtoms, rows);
+   return eamTableBytesAligned(tableWords) + (size_t)wavesPerBlock * eamCtaWaveBytes(rec, stencilAtoms, step == 1 ? rows : 0);
 }

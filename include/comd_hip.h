@@ -77,10 +77,11 @@ typedef struct EamPotentialGpu {
    real_t* rhobar;                     /* device [nTotalBoxes*maxAtoms] */
    real_t* dfEmbed;                    /* device [nTotalBoxes*maxAtoms] */
    /* cta_cell: pass 1 leaves each atom's in-cutoff neighbours (16-bit numbers in the staging order of its cell's stencil) here and pass 3
-    * reads them back instead of testing the stencil again; allocated by the first cta_cell launch */
-   unsigned short* pairRows;           /* device [nLocalBoxes*maxAtoms][pairRowLen] */
+    * reads them back instead of testing the stencil again; laid out the way pass 3's lanes consume them -- per atom [16 lanes][8 trips]
+    * words of two numbers -- so that a lane fetches its share with two 16-byte loads; allocated by the first cta_cell launch */
+   unsigned* pairRows;                 /* device [nLocalBoxes*maxAtoms][128] */
    unsigned short* pairRowCount;       /* device [nLocalBoxes*maxAtoms] */
-   int     pairRowLen;
+   int     pairRowLen;                 /* neighbours a row can hold (<= 256) */
 } EamPotentialGpu;
 
 /* gpu_types.h:98-112 */
