@@ -790,7 +790,7 @@ static void launchCompactSort(SimGpu* sim, int first, int nCells, hipStream_t st
 {
    if (nCells <= 0) return;
    if (sim->maxAtoms <= 64) {
-      hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4 * COMPACT_RUN)), dim3(256), 0, st,
+      hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4 * COMPACT_RUN_WAVE)), dim3(256), 0, st,
                          atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, first, nCells, sim->maxAtoms);
       LAUNCH_CHECK();
       return;

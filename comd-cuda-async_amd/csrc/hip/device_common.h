@@ -43,11 +43,11 @@ __device__ __forceinline__ float rcpR(float x)
 // 1/sqrt(x) to round-off from v_rsq_f64 (~2^-23) with two Newton steps / v_rsq_f32 with one.
 __device__ __forceinline__ double rsqrtR(double x)
 {
-   double y = __builtin_amdgcn_rsq(x);
-   double h = 0.5 * x;
-   y = y * __builtin_fma(-h * y, y, 1.5);
-   y = y * __builtin_fma(-h * y, y, 1.5);
-   return y;
+   // v_rsq_f64 is good to ~2^-23; with e = 1 - x y0^2 (the product x y0 rounded once, the rest in an fma), 1/sqrt(x) = y0 (1 - e)^(-1/2)
+   // = y0 (1 + e/2 + 3 e^2/8 + ...): two terms leave (5/16) e^3 ~ 2^-70.  Five operations after the seed (two Newton steps: seven).
+   const double y = __builtin_amdgcn_rsq(x);
+   const double e = __builtin_fma(-(x * y), y, 1.0);
+   return __builtin_fma(y * e, __builtin_fma(e, 0.375, 0.5), y);
 }
 __device__ __forceinline__ float rsqrtR(float x)
 {

@@ -163,12 +163,17 @@ void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__
                       int first, int nCells, int cap)
 {
    extern __shared__ int sKey[];
+   __shared__ int sFlag[COMPACT_RUN];
    const int t = threadIdx.x;
+   // the run's flags with one round trip (read one after the other they are COMPACT_RUN dependent latencies per workgroup, and almost
+   // every workgroup finds nothing to do)
+   if (t < COMPACT_RUN) sFlag[t] = blockIdx.x * COMPACT_RUN + t < nCells ? dirty[first + blockIdx.x * COMPACT_RUN + t] : 0;
+   __syncthreads();
    for (int k = 0; k < COMPACT_RUN; ++k) {
       const int idx = blockIdx.x * COMPACT_RUN + k;
       if (idx >= nCells) return;
       const int c = first + idx;
-      if (!dirty[c]) continue;                              // workgroup-uniform
+      if (!sFlag[k]) continue;                              // workgroup-uniform
       int n = nAtoms[c];
       if (n > cap) n = cap;                                  // overflow already flagged by the writer
       const size_t o = (size_t)c * cap + t;
@@ -192,17 +197,22 @@ void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__
    }
 }
 
-// Same for cap <= 64: one WAVE per run of COMPACT_RUN cells, four waves per workgroup, keys exchanged with v_readlane (no LDS, no barrier).
+// Same for cap <= 64: one WAVE per run of COMPACT_RUN_WAVE cells, four waves per workgroup, keys exchanged with v_readlane (no LDS, no barrier).
+#define COMPACT_RUN_WAVE 16
 __global__ __launch_bounds__(256)
 void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int first, int nCells, int cap)
 {
    const int lane = threadIdx.x & 63;
    const int run = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-   for (int k = 0; k < COMPACT_RUN; ++k) {
-      const int idx = run * COMPACT_RUN + k;
-      if (idx >= nCells) return;
-      const int c = first + idx;
-      if (!uniform(dirty[c])) continue;
+   // a flag per lane, one round trip for the run of COMPACT_RUN_WAVE cells (read one after the other they are as many dependent
+   // latencies, and almost every cell is clean); only the dirty ones are visited
+   const int mine = run * COMPACT_RUN_WAVE + lane;
+   const bool look = lane < COMPACT_RUN_WAVE && mine < nCells;
+   unsigned long long todo = __ballot(look && dirty[first + (look ? mine : 0)] != 0);
+   while (todo) {
+      const int k = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int c = first + run * COMPACT_RUN_WAVE + k;
       int n = uniform(nAtoms[c]);
       if (n > cap) n = cap;
       const size_t o = (size_t)c * cap + lane;
