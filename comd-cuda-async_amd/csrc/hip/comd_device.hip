@@ -789,14 +789,18 @@ static int sortBlock(int cap) { return ((cap + 63) / 64) * 64; }
 static void launchCompactSort(SimGpu* sim, int first, int nCells, hipStream_t st)
 {
    if (nCells <= 0) return;
+   // cells per wave / workgroup: the local cells are nearly all clean (one flag each), the halo cells were all just refilled
+   const bool halo = first >= sim->boxes.nLocalBoxes;
    if (sim->maxAtoms <= 64) {
-      hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4 * COMPACT_RUN_WAVE)), dim3(256), 0, st,
-                         atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, first, nCells, sim->maxAtoms);
+      const int run = halo ? 2 : COMPACT_RUN_WAVE;
+      hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4 * run)), dim3(256), 0, st,
+                         atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, first, nCells, sim->maxAtoms, run);
       LAUNCH_CHECK();
       return;
    }
-   hipLaunchKernelGGL(CompactSortCells, dim3(ceilDiv(nCells, COMPACT_RUN)), dim3(sortBlock(sim->maxAtoms)), (size_t)sortBlock(sim->maxAtoms) * sizeof(int), st,
-                      atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, first, nCells, sim->maxAtoms);
+   const int run = halo ? 1 : COMPACT_RUN;
+   hipLaunchKernelGGL(CompactSortCells, dim3(ceilDiv(nCells, run)), dim3(sortBlock(sim->maxAtoms)), (size_t)sortBlock(sim->maxAtoms) * sizeof(int), st,
+                      atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, first, nCells, sim->maxAtoms, run);
    LAUNCH_CHECK();
 }
 
@@ -815,7 +819,9 @@ extern "C" void buildAtomListGpu(SimGpu*, comdStream_t) {}
 
 extern "C" void sortAtomsGpu(SimGpu* sim, comdStream_t stream)
 {
-   launchCompactSort(sim, 0, sim->boxes.nTotalBoxes, S(stream));
+   // after the atom exchange: local cells that received atoms (few), then the halo cells (all of them)
+   launchCompactSort(sim, 0, sim->boxes.nLocalBoxes, S(stream));
+   launchCompactSort(sim, sim->boxes.nLocalBoxes, sim->boxes.nTotalBoxes - sim->boxes.nLocalBoxes, S(stream));
 }
 
 // ---- halo pack / unpack ------------------------------------------------------------------------------------------------

@@ -154,23 +154,24 @@ void UpdateLinkCells(AtomArrays at, int* __restrict__ nAtoms, const int* __restr
    dirty[c] = 1; dirty[nb] = 1;
 }
 
-// Cells [first, first + nCells), COMPACT_RUN consecutive cells per workgroup (almost all are clean: one flag read each): if a cell is
-// dirty, drop holes and rewrite the survivors in ascending-gid order (rank sort: rank = number of smaller keys; gids are unique).
-// blockDim.x >= cap.
+// Cells [first, first + nCells), `run` (<= COMPACT_RUN) consecutive cells per workgroup: if a cell is dirty, drop holes and rewrite the
+// survivors in ascending-gid order (rank sort: rank = number of smaller keys; gids are unique).  blockDim.x >= cap.
+// The host picks the run: long for the local cells (almost all clean: one flag read each), 1 for the halo cells (every one of them was
+// just refilled; eight in a row per workgroup were 40 of the 60 us this kernel took at LJ 80^3).
 #define COMPACT_RUN 8
 __global__
 void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int* __restrict__ status,
-                      int first, int nCells, int cap)
+                      int first, int nCells, int cap, int run)
 {
    extern __shared__ int sKey[];
    __shared__ int sFlag[COMPACT_RUN];
    const int t = threadIdx.x;
    // the run's flags with one round trip (read one after the other they are COMPACT_RUN dependent latencies per workgroup, and almost
    // every workgroup finds nothing to do)
-   if (t < COMPACT_RUN) sFlag[t] = blockIdx.x * COMPACT_RUN + t < nCells ? dirty[first + blockIdx.x * COMPACT_RUN + t] : 0;
+   if (t < run) sFlag[t] = blockIdx.x * run + t < nCells ? dirty[first + blockIdx.x * run + t] : 0;
    __syncthreads();
-   for (int k = 0; k < COMPACT_RUN; ++k) {
-      const int idx = blockIdx.x * COMPACT_RUN + k;
+   for (int k = 0; k < run; ++k) {
+      const int idx = blockIdx.x * run + k;
       if (idx >= nCells) return;
       const int c = first + idx;
       if (!sFlag[k]) continue;                              // workgroup-uniform
@@ -200,19 +201,19 @@ void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__
 // Same for cap <= 64: one WAVE per run of COMPACT_RUN_WAVE cells, four waves per workgroup, keys exchanged with v_readlane (no LDS, no barrier).
 #define COMPACT_RUN_WAVE 16
 __global__ __launch_bounds__(256)
-void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int first, int nCells, int cap)
+void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int first, int nCells, int cap, int run)
 {
    const int lane = threadIdx.x & 63;
-   const int run = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
-   // a flag per lane, one round trip for the run of COMPACT_RUN_WAVE cells (read one after the other they are as many dependent
+   const int wrun = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
+   // a flag per lane, one round trip for the run of `run` (<= COMPACT_RUN_WAVE) cells (read one after the other they are as many dependent
    // latencies, and almost every cell is clean); only the dirty ones are visited
-   const int mine = run * COMPACT_RUN_WAVE + lane;
-   const bool look = lane < COMPACT_RUN_WAVE && mine < nCells;
+   const int mine = wrun * run + lane;
+   const bool look = lane < run && mine < nCells;
    unsigned long long todo = __ballot(look && dirty[first + (look ? mine : 0)] != 0);
    while (todo) {
       const int k = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
-      const int c = first + run * COMPACT_RUN_WAVE + k;
+      const int c = first + wrun * run + k;
       int n = uniform(nAtoms[c]);
       if (n > cap) n = cap;
       const size_t o = (size_t)c * cap + lane;
