@@ -269,17 +269,24 @@ void ScanCellCountsBatch(const int* __restrict__ nAtoms, ScanJobs jobs)
          for (int u = 0; u < PER; ++u) { const int i = threadIdx.x + 1024 * u; if (i < m) sCnt[i] = cnt[u]; }
       }
       __syncthreads();
-      for (int base = 0; base < m; base += 1024) {
-         const int i = base + threadIdx.x;
-         const int v = i < m ? sCnt[i] : 0;
-         int incl = v;
+      // one block-wide scan per pass: a thread sums its E consecutive occupancies, the 1024 sums are scanned (wave shuffles + 16 wave
+      // totals), and the thread walks its E again (1024 occupancies per block scan took four scans and eight barriers for a face of 3.8 k cells)
+      {
+         constexpr int PER = SCAN_LDS_CELLS / 1024;
+         const int E = (m + 1023) >> 10;
+         int v[PER], sum = 0;
+#pragma unroll
+         for (int u = 0; u < PER; ++u) { const int i = threadIdx.x * E + u; v[u] = (u < E && i < m) ? sCnt[i] : 0; sum += v[u]; }
+         int incl = sum;
 #pragma unroll
          for (int d = 1; d < 64; d <<= 1) { int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
          if (lane == 63) sWave[wave] = incl;
          __syncthreads();
          int before = carry, all = 0;
          for (int w = 0; w < 16; ++w) { const int t = sWave[w]; if (w < wave) before += t; all += t; }
-         if (i < m) out[p0 + i] = before + incl - v;
+         int run = before + incl - sum;
+#pragma unroll
+         for (int u = 0; u < PER; ++u) { const int i = threadIdx.x * E + u; if (u < E && i < m) { out[p0 + i] = run; run += v[u]; } }
          carry += all;
          __syncthreads();
       }
