@@ -93,6 +93,23 @@ def test_lj_cells_larger_than_the_launch_estimate(gpu, orc, monkeypatch):
         assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
 
 
+@pytest.mark.parametrize("stencil", [128, 368])
+def test_eam_cells_whose_stencil_outgrows_the_lds_slice(gpu, orc, monkeypatch, stencil):
+    """cta_cell sizes a wave's LDS slice from the density (and trims it to where a third workgroup fits the CU); a cell whose 27-cell stencil
+    holds more atoms than the slice is walked thread-per-atom by the same wave, in pass 1 AND pass 3 (no rows are handed over for it).
+    COMD_EAM_STENCIL forces a slice that every cell (128) or part of the cells (368; the stencils of this box hold about 365 atoms) outgrow."""
+    monkeypatch.setenv("COMD_EAM_STENCIL", str(stencil))
+    with gpu.Simulation(_args(12, 1, 0.1, "cta_cell")) as sim:
+        o = orc.Oracle(12, eam=1, delta=0.1, cap=max(sim.max_atoms, 64))
+        sim.step(3)
+        o.step(3)
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * np.abs(fo).max()
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < TOL["eam_density_abs"]
+        assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < TOL["eam_dfembed_abs"]
+
+
 @pytest.mark.parametrize("env", [{"COMD_LJ_PRUNE": "0"}, {"COMD_LJ_LIST_CAP": "64"}, {"COMD_LJ_LIST_CAP": "2200"}, {}])
 def test_lj_wave_candidate_lists_and_their_fallbacks(gpu, orc, monkeypatch, env):
     """thread_atom tests only the stencil atoms within the cutoff of each wave's bounding box (LJ_WaveCandidates).  The four legs: lists
