@@ -859,6 +859,52 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned* __restr
       }
       __builtin_amdgcn_wave_barrier();
 
+      // pass 1, build of a round's rows: one atom at a time against ALL the wave's records -- lane = record; for round 0 the SR trips' records
+      // still sit in the registers they arrived in (the build runs before the next cell's loads reuse them), the atom's position is a broadcast
+      // read -- ballot + mbcnt append the hits, in record order, to the atom's row.  (Round 2 first re-read the records from the LDS for every
+      // pair of atoms: 18 VALU + 1.5 LDS instructions per atom and trip, now 13 + 0.)  Later rounds (cells of more than 16 atoms) and
+      // stencils beyond SR trips read the LDS.
+      auto buildRound = [&](const int i0, const bool fromRegs) {
+         const int nRound = ni - i0 < roundAtoms ? ni - i0 : roundAtoms;
+         for (int pa = 0; pa < nRound; ++pa) {
+            const int iA = i0 + pa;
+            const real_t xA = sp[REC * iA], yA = sp[REC * iA + 1], zA = sp[REC * iA + 2];
+            unsigned short* __restrict__ rowA = sHit + pa * rows;
+            int nA = 0;
+            int tDone = 0;
+            if (fromRegs) {
+#pragma unroll
+               for (int g = 0; g < SR; ++g) {
+                  if (g * 64 < total) {                              // wave-uniform
+                     const int t = g * 64 + lane;
+                     const real_t ax = xA - vx[g], ay = yA - vy[g], az = zA - vz[g];
+                     const real_t r2A = ax * ax + ay * ay + az * az;
+                     // records 0 .. ni-1 are the cell itself (first trip): only they can be the atom (r2 = 0); lanes past the list hold record 0
+                     const bool hitA = t < total && r2A <= a.rc2 && (g != 0 || t != iA);
+                     const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA);
+                     const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+                     if (hitA && kA < rows) rowA[kA] = (unsigned short)t;
+                     nA += __popcll(mA);
+                  }
+               }
+               tDone = SR * 64;
+            }
+            for (int t0 = tDone; t0 < total; t0 += 64) {
+               const int t = t0 + lane;
+               const int tt = t < total ? t : 0;
+               const real_t ax = xA - sp[REC * tt], ay = yA - sp[REC * tt + 1], az = zA - sp[REC * tt + 2];
+               const real_t r2A = ax * ax + ay * ay + az * az;
+               const bool hitA = t < total && r2A <= a.rc2 && t != iA;
+               const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA);
+               const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+               if (hitA && kA < rows) rowA[kA] = (unsigned short)t;
+               nA += __popcll(mA);
+            }
+            if (lane == 0) sCnt[pa] = nA;
+         }
+      };
+      if (STEP == 1 && fits) buildRound(0, true);
+
       // (b) start cell ci+1 (its description arrived during cell ci-1) and ask for the description of ci+2
       if (ci + 1 < ciEnd) {
          boxA = boxB; cntA = cntB;
@@ -899,35 +945,7 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned* __restr
                rowLo = keepLo; rowHi = keepHi; rowCnt = keepCnt;
             }
          } else {
-            // build: two atoms at a time, all 64 lanes on 64 staged records per trip (one read of each record serves both distance
-            // tests); ballot + mbcnt append the hits, in record order, to the two atoms' rows
-            for (int pa = 0; pa < nRound; pa += 2) {
-               const int iA = i0 + pa, iB = pa + 1 < nRound ? iA + 1 : iA;
-               const real_t xA = sp[REC * iA], yA = sp[REC * iA + 1], zA = sp[REC * iA + 2];
-               const real_t xB = sp[REC * iB], yB = sp[REC * iB + 1], zB = sp[REC * iB + 2];
-               unsigned short* __restrict__ rowA = sHit + pa * rows;
-               unsigned short* __restrict__ rowB = rowA + rows;
-               int nA = 0, nB = 0;
-               for (int t0 = 0; t0 < total; t0 += 64) {
-                  const int t = t0 + lane;
-                  const int tt = t < total ? t : 0;
-                  const real_t px = sp[REC * tt], py = sp[REC * tt + 1], pz = sp[REC * tt + 2];
-                  const real_t ax = xA - px, ay = yA - py, az = zA - pz;
-                  const real_t bx = xB - px, by = yB - py, bz = zB - pz;
-                  const real_t r2A = ax * ax + ay * ay + az * az, r2B = bx * bx + by * by + bz * bz;
-                  // records 0 .. ni-1 are the cell itself: only they can be the atom (r2 = 0); lanes past the list re-read record 0
-                  const bool live = t < total;
-                  const bool hitA = live && r2A <= a.rc2 && t != iA;
-                  const bool hitB = live && r2B <= a.rc2 && t != iB;
-                  const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA), mB = __builtin_amdgcn_ballot_w64(hitB);
-                  const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
-                  const int kB = nB + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
-                  if (hitA && kA < rows) rowA[kA] = (unsigned short)t;
-                  if (hitB && kB < rows) rowB[kB] = (unsigned short)t;
-                  nA += __popcll(mA); nB += __popcll(mB);
-               }
-               if (lane == 0) { sCnt[pa] = nA; sCnt[pa + 1] = nB; }      // (with an odd atom count the last B repeats A and lands in an unused row)
-            }
+            if (i0 != 0) buildRound(i0, false);             // (round 0 was built before the next cell's loads went out)
             __builtin_amdgcn_wave_barrier();
          }
          int n = have ? (STEP == 1 ? sCnt[ia] : nMine) : 0;   // in-cutoff neighbours of atom i (the same in its L lanes)
