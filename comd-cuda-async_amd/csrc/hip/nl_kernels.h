@@ -866,41 +866,41 @@ void EAM_Force_cta_cell(EamArgs a, int stencilAtoms, int rows, unsigned* __restr
       // stencils beyond SR trips read the LDS.
       auto buildRound = [&](const int i0, const bool fromRegs) {
          const int nRound = ni - i0 < roundAtoms ? ni - i0 : roundAtoms;
-         for (int pa = 0; pa < nRound; ++pa) {
-            const int iA = i0 + pa;
+         for (int pa = 0; pa < nRound; pa += 2) {             // two atoms per sweep: two independent ballot -> count -> write chains
+            const int iA = i0 + pa, iB = pa + 1 < nRound ? iA + 1 : iA;
             const real_t xA = sp[REC * iA], yA = sp[REC * iA + 1], zA = sp[REC * iA + 2];
+            const real_t xB = sp[REC * iB], yB = sp[REC * iB + 1], zB = sp[REC * iB + 2];
             unsigned short* __restrict__ rowA = sHit + pa * rows;
-            int nA = 0;
+            unsigned short* __restrict__ rowB = rowA + rows;      // (with an odd atom count the last B repeats A and lands in an unused row)
+            int nA = 0, nB = 0;
             int tDone = 0;
+            auto sweep = [&](const int t, const real_t px, const real_t py, const real_t pz, const bool first) {
+               const real_t ax = xA - px, ay = yA - py, az = zA - pz;
+               const real_t bx = xB - px, by = yB - py, bz = zB - pz;
+               const real_t r2A = ax * ax + ay * ay + az * az, r2B = bx * bx + by * by + bz * bz;
+               // records 0 .. ni-1 are the cell itself (first trip): only they can be the atom (r2 = 0); lanes past the list hold record 0
+               const bool liveT = t < total;
+               const bool hitA = liveT && r2A <= a.rc2 && (!first || t != iA);
+               const bool hitB = liveT && r2B <= a.rc2 && (!first || t != iB);
+               const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA), mB = __builtin_amdgcn_ballot_w64(hitB);
+               const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
+               const int kB = nB + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
+               if (hitA && kA < rows) rowA[kA] = (unsigned short)t;
+               if (hitB && kB < rows) rowB[kB] = (unsigned short)t;
+               nA += __popcll(mA); nB += __popcll(mB);
+            };
             if (fromRegs) {
 #pragma unroll
-               for (int g = 0; g < SR; ++g) {
-                  if (g * 64 < total) {                              // wave-uniform
-                     const int t = g * 64 + lane;
-                     const real_t ax = xA - vx[g], ay = yA - vy[g], az = zA - vz[g];
-                     const real_t r2A = ax * ax + ay * ay + az * az;
-                     // records 0 .. ni-1 are the cell itself (first trip): only they can be the atom (r2 = 0); lanes past the list hold record 0
-                     const bool hitA = t < total && r2A <= a.rc2 && (g != 0 || t != iA);
-                     const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA);
-                     const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
-                     if (hitA && kA < rows) rowA[kA] = (unsigned short)t;
-                     nA += __popcll(mA);
-                  }
-               }
+               for (int g = 0; g < SR; ++g)
+                  if (g * 64 < total) sweep(g * 64 + lane, vx[g], vy[g], vz[g], g == 0);      // wave-uniform condition
                tDone = SR * 64;
             }
             for (int t0 = tDone; t0 < total; t0 += 64) {
                const int t = t0 + lane;
                const int tt = t < total ? t : 0;
-               const real_t ax = xA - sp[REC * tt], ay = yA - sp[REC * tt + 1], az = zA - sp[REC * tt + 2];
-               const real_t r2A = ax * ax + ay * ay + az * az;
-               const bool hitA = t < total && r2A <= a.rc2 && t != iA;
-               const unsigned long long mA = __builtin_amdgcn_ballot_w64(hitA);
-               const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
-               if (hitA && kA < rows) rowA[kA] = (unsigned short)t;
-               nA += __popcll(mA);
+               sweep(t, sp[REC * tt], sp[REC * tt + 1], sp[REC * tt + 2], true);
             }
-            if (lane == 0) sCnt[pa] = nA;
+            if (lane == 0) { sCnt[pa] = nA; sCnt[pa + 1] = nB; }
          }
       };
       if (STEP == 1 && fits) buildRound(0, true);
