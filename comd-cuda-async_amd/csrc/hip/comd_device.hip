@@ -542,7 +542,15 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       pl.plCut2 = (sim->lj_pot.cutoff + n->skinDistance) * (sim->lj_pot.cutoff + n->skinDistance);
 #define LAUNCH_CTA(PLV) do { if (sim->needEnergy) hipLaunchKernelGGL((LJ_Force_cta_cell<PLV, true>), dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl); \
                             else              hipLaunchKernelGGL((LJ_Force_cta_cell<PLV, false>), dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl); } while (0)
-      if (n->slabFormat != 3)                    LAUNCH_CTA(0);
+      if (n->slabFormat != 3 && !(getenv("COMD_LJ_CTA_SLABS") && atoi(getenv("COMD_LJ_CTA_SLABS")) != 0)) {
+         // the default form: every wave stages its own box-pruned candidates (COMD_LJ_CTA_SLABS=1: the slab kernel, for A/B runs)
+         const real_t rc2Box = a.rc2 * (sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5));
+         const real_t grow = sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5);
+         const size_t ldsB = ljCtaBoxesLdsBytes(threads);
+         if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_cta_cell_boxes<true>, dim3(num_cells), dim3(threads), ldsB, S(stream), a, rc2Box, grow);
+         else                 hipLaunchKernelGGL(LJ_Force_cta_cell_boxes<false>, dim3(num_cells), dim3(threads), ldsB, S(stream), a, rc2Box, grow);
+      }
+      else if (n->slabFormat != 3)               LAUNCH_CTA(0);
       else if (n->nBuilds == 0) { fprintf(stderr, "ljForceGpu: -L needs buildNeighborListGpu before the first force call\n"); exit(-1); }
       else if (n->pairlistBuildId != n->nBuilds) LAUNCH_CTA(1);
       else                                       LAUNCH_CTA(2);

@@ -552,3 +552,109 @@ void LJ_Force_cta_cell(LjArgs a, int* __restrict__ status, LjPairlist pl)
          if (ENERGY) a.e[io] = e[u] * R(2.0) * a.eps;
       }
 }
+
+// ---------------------------------------------------------------------------------------------------
+// CTA per link cell, the default form (no -L): every WAVE of the workgroup stages its own candidates.  A wave's 64 atoms only interact with
+// the stencil atoms within the cutoff of their bounding box (about 59 % of the 27 cells for a slab of gid-ordered atoms, see
+// LJ_WaveCandidates), so the wave streams the stencil through a point-to-box test -- 64 stencil atoms per trip, one per lane -- and appends
+// the survivors (ballot + mbcnt, stencil order) to a private LDS region; whenever the region is full, and at the end of the own cell (its
+// atoms need the r2 > 0 guard), the region is consumed with the broadcast loop of the slab kernel (eight neighbours per trip).  No barrier:
+// the waves of a workgroup never wait for each other.  (The slab kernel below staged all 4000 stencil atoms for all waves, behind two
+// barriers per slab: 4.77 ms at 80^3.)
+#define LJ_CTA_WAVE_RECORDS 440            // candidates a wave can hold: 3 waves x 3 x 440 x 8 B = 31 KB per workgroup, five workgroups per CU
+static inline size_t ljCtaBoxesLdsBytes(int threads) { return (size_t)(threads / 64) * 3 * LJ_CTA_WAVE_RECORDS * sizeof(real_t); }
+
+template <bool ENERGY>
+__global__ __launch_bounds__(256)
+void LJ_Force_cta_cell_boxes(LjArgs a, real_t rc2Box, real_t grow)
+{
+   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+   real_t* wx = (real_t*)ldsRaw + (size_t)wave * 3 * LJ_CTA_WAVE_RECORDS;
+   real_t* wy = wx + LJ_CTA_WAVE_RECORDS;
+   real_t* wz = wy + LJ_CTA_WAVE_RECORDS;
+
+   const int ci = xcdRemap(blockIdx.x, gridDim.x);
+   const int iBox = a.cells ? a.cells[ci] : ci;
+   const int ni = uniform(a.nAtoms[iBox]);
+   const int nThreads = blockDim.x;
+   if (wave * 64 >= ni) return;                              // (cells of more than blockDim atoms: the wave's second atoms are wave * 64 + nThreads ...)
+
+   // each thread owns up to two atoms (cells of up to 2 * blockDim atoms): t and t + blockDim
+   real_t xi[2], yi[2], zi[2], fx[2] = {R(0.0), R(0.0)}, fy[2] = {R(0.0), R(0.0)}, fz[2] = {R(0.0), R(0.0)}, e[2] = {R(0.0), R(0.0)};
+   bool own[2];
+   const int iLast = wave * 64 + 63 < ni ? wave * 64 + 63 : ni - 1;          // idle lanes shadow an atom of the wave: the box only sees real atoms
+#pragma unroll
+   for (int u = 0; u < 2; ++u) {
+      const int i = threadIdx.x + u * nThreads;
+      own[u] = i < ni;
+      const size_t io = (size_t)iBox * a.cap + (own[u] ? i : iLast);
+      xi[u] = a.rx[io]; yi[u] = a.ry[io]; zi[u] = a.rz[io];
+   }
+   const bool second = uniform(ni > nThreads + wave * 64 ? 1 : 0) != 0;      // this wave has second atoms
+   // the wave's bounding box as centre + half width (grown by a rounding margin)
+   const real_t xlo = waveMinR(minR(xi[0], xi[1])), xhi = waveMaxR(maxR(xi[0], xi[1]));
+   const real_t ylo = waveMinR(minR(yi[0], yi[1])), yhi = waveMaxR(maxR(yi[0], yi[1]));
+   const real_t zlo = waveMinR(minR(zi[0], zi[1])), zhi = waveMaxR(maxR(zi[0], zi[1]));
+   const real_t cx = uniformR(R(0.5) * (xlo + xhi)), hx = uniformR(R(0.5) * (xhi - xlo) * grow);
+   const real_t cy = uniformR(R(0.5) * (ylo + yhi)), hy = uniformR(R(0.5) * (yhi - ylo) * grow);
+   const real_t cz = uniformR(R(0.5) * (zlo + zhi)), hz = uniformR(R(0.5) * (zhi - zlo) * grow);
+
+   LjPairlist noPl; noPl.words = nullptr; noPl.wavesMax = 0; noPl.plCut2 = R(0.0);
+   int n = 0;
+   auto consume = [&](const bool self) {
+      if (n == 0) return;
+      if (lane < 8 && n + lane < ((n + 7) & ~7)) { wx[n + lane] = FAR_AWAY; wy[n + lane] = FAR_AWAY; wz[n + lane] = FAR_AWAY; }      // pad to a multiple of 8
+      __builtin_amdgcn_wave_barrier();
+      if (self) {
+         if (!second) slabLoop<1, 0, true, ENERGY>(wx, wy, wz, n, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own);
+         else         slabLoop<2, 0, true, ENERGY>(wx, wy, wz, n, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own);
+      } else {
+         if (!second) slabLoop<1, 0, false, ENERGY>(wx, wy, wz, n, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own);
+         else         slabLoop<2, 0, false, ENERGY>(wx, wy, wz, n, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own);
+      }
+      __builtin_amdgcn_wave_barrier();
+      n = 0;
+   };
+
+   const int myBox = lane < 27 ? a.nbr[(size_t)iBox * 27 + lane] : 0;
+   const int myCount = lane < 27 ? a.nAtoms[myBox] : 0;
+   for (int k = 0; k < 27; ++k) {
+      const int jBox = __builtin_amdgcn_readlane(myBox, k), nj = __builtin_amdgcn_readlane(myCount, k);
+      const size_t base = (size_t)jBox * a.cap;
+      for (int j0 = 0; j0 < nj; j0 += 256) {
+         real_t x[4], y[4], z[4];
+#pragma unroll
+         for (int t = 0; t < 4; ++t) {
+            const int j = j0 + 64 * t + lane;
+            if (j0 + 64 * t < nj) { const size_t o = base + (j < nj ? j : 0); x[t] = a.rx[o]; y[t] = a.ry[o]; z[t] = a.rz[o]; }
+         }
+#pragma unroll
+         for (int t = 0; t < 4; ++t) {
+            const int j = j0 + 64 * t + lane;
+            if (j0 + 64 * t >= nj) break;
+            const real_t dx = maxR(R(0.0), absR(x[t] - cx) - hx);
+            const real_t dy = maxR(R(0.0), absR(y[t] - cy) - hy);
+            const real_t dz = maxR(R(0.0), absR(z[t] - cz) - hz);
+            const bool keep = j < nj && dx*dx + dy*dy + dz*dz <= rc2Box;
+            const unsigned long long mask = __ballot(keep);
+            const int add = __popcll(mask);
+            if (n + add > LJ_CTA_WAVE_RECORDS - 8) consume(k == 0);
+            const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
+            if (keep) { wx[pos] = x[t]; wy[pos] = y[t]; wz[pos] = z[t]; }
+            n += add;
+         }
+      }
+      if (k == 0) consume(true);                             // the own cell is done: everything after it needs no r2 > 0 guard
+   }
+   consume(false);
+
+   const real_t fs = LJ_FORCE_SCALE(a);
+#pragma unroll
+   for (int u = 0; u < 2; ++u)
+      if (own[u]) {
+         const size_t io = (size_t)iBox * a.cap + threadIdx.x + u * nThreads;
+         a.fx[io] = fx[u] * fs; a.fy[io] = fy[u] * fs; a.fz[io] = fz[u] * fs;
+         if (ENERGY) a.e[io] = e[u] * R(2.0) * a.eps;
+      }
+}

@@ -15,7 +15,7 @@ F = os.path.join(ROOT, "gpurun_out", "r02final")
 P = os.path.join(ROOT, "profiles")
 N = 2048000
 PATHS = [("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("lj", "cta_cell"), ("eam", "cta_cell"), ("eam", "thread_atom_nl"), ("eam", "thread_atom")]
-KERN = {("lj", "thread_atom"): ["LJ_Force_thread_atom<false, true>"], ("lj", "thread_atom_nl"): ["LJ_Force_nl_slabs<false>"], ("lj", "cta_cell"): ["LJ_Force_cta_cell<0, false>"],
+KERN = {("lj", "thread_atom"): ["LJ_Force_thread_atom<false, true>"], ("lj", "thread_atom_nl"): ["LJ_Force_nl_slabs<false>"], ("lj", "cta_cell"): ["LJ_Force_cta_cell_boxes<false>"],
         ("eam", "cta_cell"): ["EAM_Force_cta_cell<1", "EAM_Force_cta_cell<3"], ("eam", "thread_atom_nl"): ["EAM_Force_nl_lds<1", "EAM_Force_embed", "EAM_Force_nl_lds<3"],
         ("eam", "thread_atom"): ["EAM_Force_thread_atom<1", "EAM_Force_embed", "EAM_Force_thread_atom<3"]}
 

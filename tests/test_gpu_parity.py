@@ -93,6 +93,22 @@ def test_lj_cells_larger_than_the_launch_estimate(gpu, orc, monkeypatch):
         assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
 
 
+@pytest.mark.parametrize("env", [{}, {"COMD_LJ_CTA_SLABS": "1"}])
+def test_lj_cta_cell_both_forms(gpu, orc, monkeypatch, env):
+    """LJ cta_cell: the default form (every wave stages its own box-pruned candidates in a private LDS region, flushing it whenever it is
+    full -- a box this small has cells of ~200 atoms, so regions of 440 records are flushed several times per cell) and the slab form
+    that -L builds on (COMD_LJ_CTA_SLABS=1), against the oracle after a few steps."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with gpu.Simulation(_args((12, 10, 11), 0, 0.15, "cta_cell")) as sim:
+        o = orc.Oracle((12, 10, 11), eam=0, delta=0.15, cap=max(sim.max_atoms, 64))
+        sim.step(2)
+        o.step(2)
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * np.abs(fo).max()
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+
+
 @pytest.mark.parametrize("stencil", [128, 368])
 def test_eam_cells_whose_stencil_outgrows_the_lds_slice(gpu, orc, monkeypatch, stencil):
     """cta_cell sizes a wave's LDS slice from the density (and trims it to where a third workgroup fits the CU); a cell whose 27-cell stencil
