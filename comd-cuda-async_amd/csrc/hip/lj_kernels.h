@@ -436,11 +436,13 @@ template <int NA, int PL, bool SELF, bool ENERGY>
 __device__ __forceinline__ void slabLoop(const real_t* sx, const real_t* sy, const real_t* sz, int nSlab, const LjArgs& a,
                                          const real_t (&xi)[2], const real_t (&yi)[2], const real_t (&zi)[2],
                                          real_t (&fx)[2], real_t (&fy)[2], real_t (&fz)[2], real_t (&e)[2],
-                                         unsigned* __restrict__ plWords, real_t plCut2, const bool (&own)[2])
+                                         unsigned* __restrict__ plWords, real_t plCut2, const bool (&own)[2], const int jStart = 0, const int jStride = 8)
 {
-   // eight neighbours per trip: the twelve 16-byte LDS reads are issued together, then evaluated (the slab is padded to a multiple of 8)
+   // eight neighbours per trip: the twelve 16-byte LDS reads are issued together, then evaluated (the slab is padded to a multiple of 8).
+   // jStart / jStride: the lanes of a replicated wave take every jStride / 8-th trip (then nSlab is a multiple of jStride and the reads are
+   // per-lane instead of broadcasts); the default is the wave-wide walk.
    unsigned word = 0;
-   for (int j = 0; j < nSlab; j += 8) {
+   for (int j = jStart; j < nSlab; j += jStride) {
       const int trip = j >> 3;
       if (PL == 2) {
          if ((trip & 31) == 0) word = (unsigned)__builtin_amdgcn_readfirstlane((int)plWords[trip >> 5]);
@@ -592,6 +594,20 @@ void LJ_Force_cta_cell_boxes(LjArgs a, real_t rc2Box, real_t grow)
       xi[u] = a.rx[io]; yi[u] = a.ry[io]; zi[u] = a.rz[io];
    }
    const bool second = uniform(ni > nThreads + wave * 64 ? 1 : 0) != 0;      // this wave has second atoms
+   // an under-filled wave (the tail of a cell: 20 of 64 lanes at 148 atoms) replicates its atoms G times across the lanes and replica g
+   // takes every G-th trip of the staged candidates; the replicas are added with ds_bpermute at the end
+   const int m = ni - wave * 64 < 64 ? ni - wave * 64 : 64;
+   const bool replicated = !second && m <= 32;
+   const int G = replicated ? (64 / m < 4 ? 64 / m : 4) : 1;
+   const int g = replicated ? lane / m : 0, ai = replicated ? lane - g * m : lane;
+   const bool validRep = g < G;
+   if (replicated) {
+      const size_t io = (size_t)iBox * a.cap + wave * 64 + (validRep ? ai : 0);
+      xi[0] = a.rx[io]; yi[0] = a.ry[io]; zi[0] = a.rz[io];
+      xi[1] = xi[0]; yi[1] = yi[0]; zi[1] = zi[0];
+      own[0] = validRep; own[1] = false;
+   }
+   const int jStart = 8 * (validRep ? g : 0), jStride = 8 * G;
    // the wave's bounding box as centre + half width (grown by a rounding margin)
    const real_t xlo = waveMinR(minR(xi[0], xi[1])), xhi = waveMaxR(maxR(xi[0], xi[1]));
    const real_t ylo = waveMinR(minR(yi[0], yi[1])), yhi = waveMaxR(maxR(yi[0], yi[1]));
@@ -604,14 +620,15 @@ void LJ_Force_cta_cell_boxes(LjArgs a, real_t rc2Box, real_t grow)
    int n = 0;
    auto consume = [&](const bool self) {
       if (n == 0) return;
-      if (lane < 8 && n + lane < ((n + 7) & ~7)) { wx[n + lane] = FAR_AWAY; wy[n + lane] = FAR_AWAY; wz[n + lane] = FAR_AWAY; }      // pad to a multiple of 8
+      const int nPad = ((n + jStride - 1) / jStride) * jStride;                 // whole trips for every replica (jStride <= 32)
+      if (lane < 32 && n + lane < nPad) { wx[n + lane] = FAR_AWAY; wy[n + lane] = FAR_AWAY; wz[n + lane] = FAR_AWAY; }
       __builtin_amdgcn_wave_barrier();
       if (self) {
-         if (!second) slabLoop<1, 0, true, ENERGY>(wx, wy, wz, n, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own);
-         else         slabLoop<2, 0, true, ENERGY>(wx, wy, wz, n, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own);
+         if (!second) slabLoop<1, 0, true, ENERGY>(wx, wy, wz, nPad, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own, jStart, jStride);
+         else         slabLoop<2, 0, true, ENERGY>(wx, wy, wz, nPad, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own, jStart, jStride);
       } else {
-         if (!second) slabLoop<1, 0, false, ENERGY>(wx, wy, wz, n, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own);
-         else         slabLoop<2, 0, false, ENERGY>(wx, wy, wz, n, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own);
+         if (!second) slabLoop<1, 0, false, ENERGY>(wx, wy, wz, nPad, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own, jStart, jStride);
+         else         slabLoop<2, 0, false, ENERGY>(wx, wy, wz, nPad, a, xi, yi, zi, fx, fy, fz, e, nullptr, noPl.plCut2, own, jStart, jStride);
       }
       __builtin_amdgcn_wave_barrier();
       n = 0;
@@ -639,7 +656,7 @@ void LJ_Force_cta_cell_boxes(LjArgs a, real_t rc2Box, real_t grow)
             const bool keep = j < nj && dx*dx + dy*dy + dz*dz <= rc2Box;
             const unsigned long long mask = __ballot(keep);
             const int add = __popcll(mask);
-            if (n + add > LJ_CTA_WAVE_RECORDS - 8) consume(k == 0);
+            if (n + add > LJ_CTA_WAVE_RECORDS - 32) consume(k == 0);     // (room for the padding to whole trips of every replica)
             const int pos = n + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
             if (keep) { wx[pos] = x[t]; wy[pos] = y[t]; wz[pos] = z[t]; }
             n += add;
@@ -650,6 +667,20 @@ void LJ_Force_cta_cell_boxes(LjArgs a, real_t rc2Box, real_t grow)
    consume(false);
 
    const real_t fs = LJ_FORCE_SCALE(a);
+   if (replicated) {
+      real_t tx = fx[0], ty = fy[0], tz = fz[0], te = e[0];
+      for (int r = 1; r < G; ++r) {                       // all lanes take part; only lanes < m keep the result
+         const int src = (ai + r * m) & 63;
+         tx += bpermuteR(fx[0], src); ty += bpermuteR(fy[0], src); tz += bpermuteR(fz[0], src);
+         if (ENERGY) te += bpermuteR(e[0], src);
+      }
+      if (lane < m) {
+         const size_t io = (size_t)iBox * a.cap + wave * 64 + lane;
+         a.fx[io] = tx * fs; a.fy[io] = ty * fs; a.fz[io] = tz * fs;
+         if (ENERGY) a.e[io] = te * R(2.0) * a.eps;
+      }
+      return;
+   }
 #pragma unroll
    for (int u = 0; u < 2; ++u)
       if (own[u]) {
