@@ -164,6 +164,7 @@ __device__ __forceinline__ float uniformR(float v) { return __int_as_float(__bui
 // this kernel bandwidth-bound at 0.39 ms).  Boxes are held as centre + half width: the distance of a point to the box along an axis is
 // max(0, |x - c| - h).
 #define LJ_LIST_CHUNKS 4                      // lists built per sweep (cells of up to 256 atoms need one sweep)
+#define LJ_LIST_TRIPS 3                       // 64-atom trips of a stencil cell held in registers (and prefetched a cell ahead)
 __global__ __launch_bounds__(256)
 void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
 {
@@ -204,38 +205,38 @@ void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
             cz[c] = uniformR(R(0.5) * (zlo + zhi)); hz[c] = uniformR(R(0.5) * (zhi - zlo) * w.grow);
          }
       }
-      // cells of up to 256 atoms in one round of four 64-atom trips, loaded one cell ahead of the tests
-      real_t x[4], y[4], z[4], xn[4], yn[4], zn[4];
+      // cells of up to 64 * LJ_LIST_TRIPS atoms in one round of 64-atom trips, loaded one cell ahead of the tests
+      real_t x[LJ_LIST_TRIPS], y[LJ_LIST_TRIPS], z[LJ_LIST_TRIPS], xn[LJ_LIST_TRIPS], yn[LJ_LIST_TRIPS], zn[LJ_LIST_TRIPS];
       int jBox = __builtin_amdgcn_readlane(myBox, 0), nj = __builtin_amdgcn_readlane(myCount, 0);
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
          const int j = 64 * t + lane;
          if (64 * t < nj) { const size_t o = (size_t)jBox * a.cap + (j < nj ? j : 0); xn[t] = a.rx[o]; yn[t] = a.ry[o]; zn[t] = a.rz[o]; }
       }
       for (int k = 0; k < 27; ++k) {
          const int jBoxNow = jBox, njNow = nj;
 #pragma unroll
-         for (int t = 0; t < 4; ++t) { x[t] = xn[t]; y[t] = yn[t]; z[t] = zn[t]; }
+         for (int t = 0; t < LJ_LIST_TRIPS; ++t) { x[t] = xn[t]; y[t] = yn[t]; z[t] = zn[t]; }
          if (k + 1 < 27) {
             jBox = __builtin_amdgcn_readlane(myBox, k + 1); nj = __builtin_amdgcn_readlane(myCount, k + 1);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
                const int j = 64 * t + lane;
                if (64 * t < nj) { const size_t o = (size_t)jBox * a.cap + (j < nj ? j : 0); xn[t] = a.rx[o]; yn[t] = a.ry[o]; zn[t] = a.rz[o]; }
             }
          }
          const size_t base = (size_t)jBoxNow * a.cap;
-         for (int j0 = 0; j0 < njNow; j0 += 256) {
-            if (j0 > 0) {                                  // cells beyond 256 atoms: the later rounds are loaded on the spot
+         for (int j0 = 0; j0 < njNow; j0 += 64 * LJ_LIST_TRIPS) {
+            if (j0 > 0) {                                  // fuller cells: the later rounds are loaded on the spot
 #pragma unroll
-               for (int t = 0; t < 4; ++t) {
+               for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
                   const int j = j0 + 64 * t + lane;
                   const size_t o = base + (j < njNow ? j : 0);
                   x[t] = a.rx[o]; y[t] = a.ry[o]; z[t] = a.rz[o];
                }
             }
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
                const int j = j0 + 64 * t + lane;
                if (j0 + 64 * t >= njNow) break;
                const unsigned entry = (unsigned)(((size_t)jBoxNow * w.capP + j) * sizeof(LjPos4));
