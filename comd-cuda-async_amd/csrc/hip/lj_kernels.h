@@ -189,10 +189,9 @@ void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
    for (int c0 = 0; c0 < nChunks; c0 += LJ_LIST_CHUNKS) {
       real_t cx[LJ_LIST_CHUNKS], cy[LJ_LIST_CHUNKS], cz[LJ_LIST_CHUNKS], hx[LJ_LIST_CHUNKS], hy[LJ_LIST_CHUNKS], hz[LJ_LIST_CHUNKS];
       int n[LJ_LIST_CHUNKS], nSelf[LJ_LIST_CHUNKS];
-      bool fits[LJ_LIST_CHUNKS];
 #pragma unroll
       for (int c = 0; c < LJ_LIST_CHUNKS; ++c) {
-         n[c] = 0; nSelf[c] = 0; fits[c] = c0 + c < nChunks;
+         n[c] = 0; nSelf[c] = 0;
          cx[c] = cy[c] = cz[c] = hx[c] = hy[c] = hz[c] = R(0.0);
          if (c0 + c < nChunks) {
             const int iSlot = (c0 + c) * 64 + lane;
@@ -242,17 +241,18 @@ void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
                const unsigned entry = (unsigned)(((size_t)jBoxNow * w.capP + j) * sizeof(LjPos4));
 #pragma unroll
                for (int c = 0; c < LJ_LIST_CHUNKS; ++c) {
-                  if (!fits[c]) continue;
+                  if (c0 + c >= nChunks) continue;                // (wave-uniform)
                   const real_t dx = maxR(R(0.0), absR(x[t] - cx[c]) - hx[c]);
                   const real_t dy = maxR(R(0.0), absR(y[t] - cy[c]) - hy[c]);
                   const real_t dz = maxR(R(0.0), absR(z[t] - cz[c]) - hz[c]);
                   const bool keep = j < njNow && dx*dx + dy*dy + dz*dz <= w.rc2Box;
                   const unsigned long long mask = __ballot(keep);
-                  const int add = __popcll(mask);
-                  if (n[c] + add > w.candCap) { fits[c] = false; continue; }
+                  // no early-out on a full row: the count keeps running (a row that ends up too long is marked at the end), the store is
+                  // what is guarded -- nine independent test -> ballot -> count -> store chains per cell for the scheduler to interleave
+                  const int pos = n[c] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
                   unsigned* __restrict__ L = w.cand + (size_t)(iBox * w.wavesMax + c0 + c) * w.candCap;
-                  if (keep) L[n[c] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u))] = entry;
-                  n[c] += add;
+                  if (keep && pos < w.candCap) L[pos] = entry;
+                  n[c] += __popcll(mask);
                }
             }
          }
@@ -263,7 +263,7 @@ void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
       }
 #pragma unroll
       for (int c = 0; c < LJ_LIST_CHUNKS; ++c)
-         if (c0 + c < nChunks && lane == 0) w.count[iBox * w.wavesMax + c0 + c] = fits[c] ? make_int2(nSelf[c], n[c]) : make_int2(0, -1);
+         if (c0 + c < nChunks && lane == 0) w.count[iBox * w.wavesMax + c0 + c] = n[c] <= w.candCap ? make_int2(nSelf[c], n[c]) : make_int2(0, -1);
    }
 }
 
