@@ -15,6 +15,7 @@
 #include "eam_kernels.h"
 #include "step_kernels.h"
 #include "nl_kernels.h"
+#include "eam_brick_kernels.h"
 
 static int g_rank = 0;
 
@@ -359,7 +360,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
-                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1] };
+                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1] };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
@@ -602,6 +603,83 @@ static void launchEamThreadAtom(SimGpu* sim, const EamArgs& a, int num_cells, hi
    LAUNCH_CHECK();
 }
 
+// cta_cell, brick form (eam_brick_kernels.h): a workgroup stages the cells around a brick of 1 x BY x BZ cells once and its waves take the
+// brick's cells one at a time.  COMD_EAM_BRICK="by,bz" overrides the brick (experiments), COMD_EAM_BRICK_WAVES the waves per workgroup.
+template <int STEP>
+static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* cells_list, hipStream_t st, int spline)
+{
+   const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
+   const bool tablesInLds = !spline && tableBytes <= 32 * 1024;      // funcfl tables (500 samples) live in the LDS; setfl (10000) and spline coefficients stay in L2
+   const bool sameGrid = a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+   size_t tableDoubles = 0;
+   if (tablesInLds) tableDoubles = STEP == 1 ? (size_t)2 * (a.rho.n + 3) + (sameGrid ? 0 : (a.phi.n + 3 - (a.rho.n + 3))) : (size_t)(a.rho.n + 3);
+   EamBrickArgs b; memset(&b, 0, sizeof b);
+   for (int k = 0; k < 3; ++k) { b.geom.g[k] = sim->boxes.gridSize[k]; b.geom.lmin[k] = sim->boxes.localMin[k]; b.geom.lmax[k] = sim->boxes.localMax[k]; b.geom.inv[k] = sim->boxes.invBoxSize[k]; }
+   b.geom.nLocal = sim->boxes.nLocalBoxes; b.geom.nTotal = sim->boxes.nTotalBoxes;
+   b.geom.lookup = sim->boxes.boxIDLookUp; b.geom.reverse = sim->boxes.boxIDLookUpReverse;
+   b.by = 4; b.bz = 2;
+   { const char* e = getenv("COMD_EAM_BRICK"); int y = 0, z = 0; if (e && sscanf(e, "%d,%d", &y, &z) == 2 && y >= 1 && z >= 1 && 3 * (y + 2) * (z + 2) <= EAM_BRICK_MAX_CELLS && y * z <= 64) { b.by = y; b.bz = z; } }
+   b.nby = ceilDiv(b.geom.g[1], b.by); b.nbz = ceilDiv(b.geom.g[2], b.bz);
+   // the image: the block's cells at the perfect-lattice density + 15 % (the sum over 72 cells fluctuates far less than one cell) + 48
+   const double cellVol = 1.0 / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);
+   const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
+   const int blockCells = 3 * (b.by + 2) * (b.bz + 2);
+   const double perBlock = blockCells * cellVol * 4.0 / (lat * lat * lat);
+   b.imageCap = (((int)(perBlock * 1.15) + 48 + 7) / 8) * 8;
+   if (b.imageCap < 256) b.imageCap = 256;
+   if (b.imageCap > 4096) b.imageCap = 4096;                 // 16-bit numbers would reach 65535; beyond 4096 records the cells take the thread-per-atom form
+   { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) b.imageCap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force the fallback
+   // rows per atom: the cutoff sphere at that density + 50 %, a multiple of 8
+   const double rc = sim->eam_pot.cutoff;
+   int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
+   if (rows < 32) rows = 32;
+   if (rows > 256) rows = 256;
+   if (rows > 16 * 16) rows = 256;
+   if (!sim->eam_pot.pairRows) {                             // rows pass 1 leaves for pass 3: [slot][lane of the atom][trip] words
+      const size_t slotsLocal = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
+      sim->eam_pot.pairRows = dalloc<unsigned>(slotsLocal * EAM_ROW_WORDS, false);
+      sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal);
+      sim->eam_pot.pairRowLen = rows;
+   }
+   b.rows = sim->eam_pot.pairRowLen; b.rowsG = sim->eam_pot.pairRows; b.rowCountG = sim->eam_pot.pairRowCount;
+   b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
+   { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
+   if (cells_list) {      // a launch over a cell list (-a 1): mark the cells, every brick looks at its own
+      if (!sim->eam_pot.cellSel) sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes);
+      b.sel = sim->eam_pot.cellSel; b.tag = ++sim->eam_pot.selTag;
+      hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(num_cells, 256)), dim3(256), 0, st, cells_list, num_cells, sim->eam_pot.cellSel, b.tag);
+   }
+   int waves = 4;
+   { const char* e = getenv("COMD_EAM_BRICK_WAVES"); if (e && atoi(e) >= 4 && atoi(e) <= 16) waves = atoi(e); }
+   // The LDS decides how many workgroups share a CU (1280-byte granules, 160 KB per CU): walk the image down, never below the density + 8 % + 24,
+   // to where pass 1 or pass 3 gains a workgroup.  Both passes must use the same image (a brick either fits it or takes the other form, in both).
+   if (!getenv("COMD_EAM_IMAGE")) {
+      const size_t t1 = tablesInLds ? (size_t)2 * (a.rho.n + 3) + (sameGrid ? 0 : (a.phi.n + 3 - (a.rho.n + 3))) : 0, t3 = tablesInLds ? (size_t)(a.rho.n + 3) : 0;
+      auto perCu = [&](int step, int cap) {
+         const size_t bts = eamBrickLdsBytes(step, step == 1 ? t1 : t3, cap, b.rows, waves);
+         return bts > 160 * 1024 ? 0 : (int)(160 * 1024 / (((bts + 1279) / 1280) * 1280));
+      };
+      const int lo = (((int)(perBlock * 1.08) + 24 + 7) / 8) * 8;
+      int best = b.imageCap, bestScore = perCu(1, best) + perCu(3, best);
+      for (int cap = b.imageCap - 8; cap >= lo && cap >= 256; cap -= 8) {
+         const int score = perCu(1, cap) + perCu(3, cap);
+         if (score > bestScore) { bestScore = score; best = cap; }
+      }
+      b.imageCap = best;
+   }
+   const size_t lds = eamBrickLdsBytes(STEP, tableDoubles, b.imageCap, b.rows, waves);
+   if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
+   const int grid = b.geom.g[0] * b.nby * b.nbz;
+#define COMD_LAUNCH_EAM_BRICK(TAB, SPL) do { \
+      static size_t attrSet = 0; \
+      if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_brick<STEP, TAB, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; } \
+      hipLaunchKernelGGL((EAM_Force_cta_brick<STEP, TAB, SPL>), dim3(grid), dim3(64 * waves), lds, st, a, b); } while (0)
+   if (spline)           COMD_LAUNCH_EAM_BRICK(false, true);
+   else if (tablesInLds) COMD_LAUNCH_EAM_BRICK(true, false);
+   else                  COMD_LAUNCH_EAM_BRICK(false, false);
+#undef COMD_LAUNCH_EAM_BRICK
+}
+
 template <int STEP>
 static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int method, hipStream_t st, int spline)
 {
@@ -640,8 +718,11 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (spline)                       hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false, true>), dim3(nBlocks), dim3(256), 0, st, a, nl);
       else if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true, false>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
       else                              hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
+   } else if (method == CTA_CELL && !(getenv("COMD_EAM_CTA") && !strcmp(getenv("COMD_EAM_CTA"), "cell"))
+              && (double)sim->boxes.nTotalBoxes * sim->maxAtoms * sizeof(real_t) < 4294967296.0) {      // (the brick kernel stages with 32-bit byte offsets)
+      launchEamBrick<STEP>(sim, a, num_cells, cells_list, st, spline);
    } else if (method == CTA_CELL) {
-      // wave per cell, neighbour rows built on the fly in the LDS (nl_kernels.h EAM_Force_cta_cell); any cell capacity
+      // COMD_EAM_CTA=cell: round 2's form, a wave stages the stencil of every cell for itself (nl_kernels.h EAM_Force_cta_cell); kept for A/B runs
       const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
       const bool tablesInLds = !spline && tableBytes <= 32 * 1024;      // funcfl tables (500 samples) live in the LDS; setfl (10000) and spline coefficients stay in L2
       const bool sameGrid = a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
