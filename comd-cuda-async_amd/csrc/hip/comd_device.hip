@@ -291,6 +291,7 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
    } else {
       sim->boundary_stream = nullptr; sim->interior_stream = nullptr;
    }
+   HIP_CHECK(hipDeviceSynchronize());            // the zeroing above is done before any non-blocking stream can touch these arrays
 }
 
 extern "C" void SetBoundaryCells(SimGpu* sim, int nBoundary, const int* boundary, int nInterior, const int* interior,
@@ -638,14 +639,19 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    if (!sim->eam_pot.pairRows) {                             // rows pass 1 leaves for pass 3: [slot][lane of the atom][trip] words
       const size_t slotsLocal = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
       sim->eam_pot.pairRows = dalloc<unsigned>(slotsLocal * EAM_ROW_WORDS, false);
-      sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal);
+      sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal, false);      // (written by pass 1 before pass 3 reads it; no zeroing that could race with that)
       sim->eam_pot.pairRowLen = rows;
    }
    b.rows = sim->eam_pot.pairRowLen; b.rowsG = sim->eam_pot.pairRows; b.rowCountG = sim->eam_pot.pairRowCount;
    b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
    { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
    if (cells_list) {      // a launch over a cell list (-a 1): mark the cells, every brick looks at its own
-      if (!sim->eam_pot.cellSel) sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes);
+      if (!sim->eam_pot.cellSel) {
+         // zeroed ON THE LAUNCH STREAM: hipMemset returns before the device has finished, and the -a 1 streams are non-blocking -- a zeroing on
+         // the null stream can land after the marks of the first launch (seen once in four-rank runs: a first force evaluation that skipped cells)
+         sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
+         HIP_CHECK(hipMemsetAsync(sim->eam_pot.cellSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(int), st));
+      }
       b.sel = sim->eam_pot.cellSel; b.tag = ++sim->eam_pot.selTag;
       hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(num_cells, 256)), dim3(256), 0, st, cells_list, num_cells, sim->eam_pot.cellSel, b.tag);
    }
@@ -745,7 +751,7 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (!sim->eam_pot.pairRows) {                          // first cta_cell launch: rows pass 1 leaves for pass 3
          const size_t slotsLocal = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
          sim->eam_pot.pairRows = dalloc<unsigned>(slotsLocal * EAM_ROW_WORDS, false);
-         sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal);
+         sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal, false);
          sim->eam_pot.pairRowLen = rows;
       }
       // The LDS slice decides how many workgroups share a CU (gfx950 hands the LDS out in 1280-byte granules, 160 KB per CU), and these kernels

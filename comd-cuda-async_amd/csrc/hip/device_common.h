@@ -80,6 +80,19 @@ __device__ __forceinline__ float bpermuteR(float v, int srcLane)
    return __int_as_float(__builtin_amdgcn_ds_bpermute(srcLane << 2, __float_as_int(v)));
 }
 
+// the same with the byte address (4 * source lane) already formed: one address serves several values
+__device__ __forceinline__ double bpermuteAddrR(double v, int addr)
+{
+   int lo = __double2loint(v), hi = __double2hiint(v);
+   lo = __builtin_amdgcn_ds_bpermute(addr, lo);
+   hi = __builtin_amdgcn_ds_bpermute(addr, hi);
+   return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float bpermuteAddrR(float v, int addr)
+{
+   return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+}
+
 // butterfly sum over the 64 lanes; every lane ends with the total, in a fixed order
 __device__ __forceinline__ real_t waveSum(real_t v)
 {

@@ -22,9 +22,6 @@
 #define EAM_BRICK_MAX_CELLS 128           // cells of the staged block: 3 * (BY + 2) * (BZ + 2) <= 128
 #define EAM_BRICK_SR 6                    // records a lane keeps in registers during the build (384 per wave; larger stencils read the LDS)
 #define EAM_BRICK_STAGE 8                 // staging iterations with all loads in flight (256 threads x 8 = 128 cells x 16 slots)
-#ifndef EAM_BRICK_LDS_REDUCE
-#define EAM_BRICK_LDS_REDUCE 0            // 1: the lanes of an atom add their partial sums through the LDS; 0: shift-down tree of ds_bpermutes
-#endif
 
 struct EamBrickArgs {
    CellGeom geom;                         // local grid (+ -H lookup tables, device pointers)
@@ -41,12 +38,10 @@ struct EamBrickArgs {
 };
 
 __host__ __device__ static inline int eamBrickRowStrideL(int rows) { return rows + 8; }      // LDS row stride (entries): 16 bytes of padding spread the atoms' rows over the banks
-// per wave: pass 1 [16][stride] rows + [16] counts, overlaid after the evaluation by [5][64] partial sums; pass 3 [3][64] partial sums
+// per wave, pass 1 only: [16][stride] rows + [16] counts
 __host__ __device__ static inline size_t eamBrickWaveBytes(int step, int rows)
 {
-   const size_t red = EAM_BRICK_LDS_REDUCE ? (size_t)(step == 1 ? 5 : 3) * 64 * sizeof(real_t) : 0;
-   const size_t build = step == 1 ? (size_t)16 * eamBrickRowStrideL(rows) * 2 + 64 : 0;
-   return ((red > build ? red : build) + 15) & ~(size_t)15;
+   return step == 1 ? (((size_t)16 * eamBrickRowStrideL(rows) * 2 + 64 + 15) & ~(size_t)15) : 0;
 }
 __host__ __device__ static inline size_t eamBrickSharedBytes(int step, int imageCap)
 {
@@ -87,7 +82,6 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
    int* sMisc = sBox + EAM_BRICK_MAX_CELLS;                  // [16]: 0/1 selection mask, 4 records in the image
    unsigned char* sList = (unsigned char*)(sMisc + 16);      // [64] selected cells of the brick, compacted
    unsigned short* sHit = (unsigned short*)(sList + 64 + (size_t)wave * eamBrickWaveBytes(STEP, b.rows));      // pass 1: [16][stride] rows under construction
-   real_t* sRed = (real_t*)sHit;                             // [5 | 3][64] partial sums at the end of a round (EAM_BRICK_LDS_REDUCE; pass 1: the rows are no longer needed by then)
    const int strideL = eamBrickRowStrideL(b.rows);
    int* sCnt = (int*)(sHit + 16 * strideL);                  // pass 1: [16] neighbours of the round's atoms
 
@@ -262,23 +256,9 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG + cellSlot * EAM_ROW_WORDS);
          p.lo = src[ii * (EAM_ROW_WORDS / 4) + 2u * q]; p.hi = src[ii * (EAM_ROW_WORDS / 4) + 2u * q + 1u];
          // pass 3 adds to the forces of pass 1: ask for them now, a whole cell of arithmetic before they are needed
-         if (EAM_BRICK_LDS_REDUCE) { if (q < 3) p.f0x = ((q == 0 ? a.fx : q == 1 ? a.fy : a.fz) + cellSlot)[ii]; }
-         else if (q == 0) { p.f0x = (a.fx + cellSlot)[ii]; p.f0y = (a.fy + cellSlot)[ii]; p.f0z = (a.fz + cellSlot)[ii]; }
+         if (q == 0) { p.f0x = (a.fx + cellSlot)[ii]; p.f0y = (a.fy + cellSlot)[ii]; p.f0z = (a.fz + cellSlot)[ii]; }
       }
    };
-   // pass 1, embedding of the atoms of the previous round (pass 2, EAM_Force_embed): the four table samples around rhobar are requested when a
-   // round's sums are complete and used at the end of the NEXT round, so that no wave waits for them
-   bool pend = false; size_t pIo = 0; real_t pR = R(0.0), pE = R(0.0), pv0 = R(0.0), pv1 = R(0.0), pv2 = R(0.0), pv3 = R(0.0);
-   auto finishEmbed = [&]() {
-      if (pend) {
-         const real_t g1 = pv2 - pv0, g2 = pv3 - pv1;
-         const real_t F = pv1 + R(0.5) * pR * (g1 + pR * (pv2 + pv0 - R(2.0) * pv1));
-         const real_t dF = (g1 + pR * (g2 - g1)) * a.f.invDxHalf;
-         a.dfEmbed[pIo] = dF; a.e[pIo] = pE + F;
-         pend = false;
-      }
-   };
-
    // ---- the waves take the brick's selected cells in turn: wave w the cells w, w + nWaves, ... -----------------------------------------------
    auto cellHeader = [&](const int pick, int& iBox, int& ownStart, int& ni, int& yh, int& zh) {
       const int cl = sList[pick];
@@ -322,12 +302,11 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
                const real_t ax = xA - px, ay = yA - py, az = zA - pz;
                const real_t bx_ = xB - px, by_ = yB - py, bz_ = zB - pz;
                const real_t r2A = ax * ax + ay * ay + az * az, r2B = bx_ * bx_ + by_ * by_ + bz_ * bz_;
-               // (lanes past the stencil hold a record at FAR_AWAY; branch-free: the predicates are and-ed as masks)
-               const bool hitA = (r2A <= a.rc2) & (r != recA);
-               const bool hitB = (r2B <= a.rc2) & (r != recB);
-               // (ballot of a compare IS the compare's mask; ballot of the and-ed bool costs a cndmask and a second compare)
+               // Lanes past the stencil hold a record at FAR_AWAY.  The ballot of a compare IS the compare's mask (the ballot of an and-ed bool costs
+               // a cndmask and a second compare), and inverse_ballot turns the and-ed mask into the exec mask of the append without a VALU instruction.
                const unsigned long long mA = __builtin_amdgcn_ballot_w64(r2A <= a.rc2) & __builtin_amdgcn_ballot_w64(r != recA);
                const unsigned long long mB = __builtin_amdgcn_ballot_w64(r2B <= a.rc2) & __builtin_amdgcn_ballot_w64(r != recB);
+               const bool hitA = __builtin_amdgcn_inverse_ballot_w64(mA), hitB = __builtin_amdgcn_inverse_ballot_w64(mB);
                const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
                const int kB = nB + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
                if (hitA && kA < b.rows) rowA[kA] = (unsigned short)r;
@@ -379,7 +358,6 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
             }
             __builtin_amdgcn_wave_barrier();
             n = have ? sCnt[ia] : 0;
-            if (lane < nRound) (b.rowCountG + cellSlot)[(unsigned)(i0 + lane)] = (unsigned short)(sCnt[lane] < b.rows ? sCnt[lane] : b.rows);
          } else {
             n = have ? cur.n : 0;
          }
@@ -437,72 +415,61 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
                evalTrip((int)(wReg[u] & 0xffffu), h1 ? (int)(wReg[u] >> 16) : recI, h1);
             }
          }
-         if (STEP == 1 && have) {      // hand the lane's words to pass 3 (the second 16 bytes only when a trip beyond the fourth was made)
-            uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG + cellSlot * EAM_ROW_WORDS) + ii * (EAM_ROW_WORDS / 4) + 2u * (unsigned)q;
-            if (q < nPairs) dst[0] = make_uint4(wReg[0], wReg[1], wReg[2], wReg[3]);
-            if (4 * L + q < nPairs) dst[1] = make_uint4(wReg[4], wReg[5], wReg[6], wReg[7]);
-         }
-#if EAM_BRICK_LDS_REDUCE
-         // The L lanes of an atom are consecutive.  Their partial sums meet in the LDS: every lane leaves its partials in [value][lane], then lane q of
-         // the atom adds value q over the atom's lanes, in lane order, and stores it -- q = 0, 1, 2: the force components, q = 3 (pass 1): energy and density
-         __builtin_amdgcn_wave_barrier();
-         sRed[lane] = fx; sRed[64 + lane] = fy; sRed[128 + lane] = fz;
-         if (STEP == 1) { sRed[192 + lane] = e; sRed[256 + lane] = rb; }
-         __builtin_amdgcn_wave_barrier();
-         real_t s0 = R(0.0), rbs = R(0.0);
-         if (have && q < (STEP == 1 ? 4 : 3)) {
-            const real_t* __restrict__ src = sRed + (q < 3 ? q : 3) * 64 + (lane - q);
-            for (int j0 = 0; j0 < L; j0 += 4) {               // four reads in flight per trip (L is wave-uniform; the tail repeats the last lane, unused)
-               const int j1 = j0 + 1 < L ? j0 + 1 : j0, j2 = j0 + 2 < L ? j0 + 2 : j0, j3 = j0 + 3 < L ? j0 + 3 : j0;
-               const real_t v0 = src[j0], v1 = src[j1], v2 = src[j2], v3 = src[j3];
-               real_t w0 = R(0.0), w1 = R(0.0), w2 = R(0.0), w3 = R(0.0);
-               if (STEP == 1) { w0 = src[64 + j0]; w1 = src[64 + j1]; w2 = src[64 + j2]; w3 = src[64 + j3]; }      // (used by q = 3 only: density beside energy)
-               s0 += v0; if (j0 + 1 < L) s0 += v1; if (j0 + 2 < L) s0 += v2; if (j0 + 3 < L) s0 += v3;
-               if (STEP == 1) { rbs += w0; if (j0 + 1 < L) rbs += w1; if (j0 + 2 < L) rbs += w2; if (j0 + 3 < L) rbs += w3; }
-            }
-         }
-         const bool embedLane = have && q == 3;
-         const real_t eSum = s0;
-         if (have && q < 3) ((q == 0 ? a.fx : q == 1 ? a.fy : a.fz) + cellSlot)[ii] = STEP == 3 ? cur.f0x + s0 : s0;
-#else
-         // the L lanes of an atom are consecutive: a shift-down tree adds them into the first (quad-permute DPP when L is 4)
+         // The L lanes of an atom are consecutive: a shift-down tree adds them into the first (quad-permute DPP when L is 4).  One ds_bpermute address
+         // and one weight per step serve all the sums: lane q takes lane q + d with weight 1 while q + d < L, else weight 0 (what it reads there is
+         // another atom's finite partial sum) -- an fma where round 2's tree spent two selects and an add per value; steps with d >= L are skipped.
          if (L == 4) {
             fx = quadSum(fx); fy = quadSum(fy); fz = quadSum(fz);
             if (STEP == 1) { e = quadSum(e); rb = quadSum(rb); }
          } else {
 #pragma unroll
             for (int d = 1; d < 16; d <<= 1) {
-               const bool take = q + d < L;
-               const real_t tx = __shfl_down(fx, d), ty = __shfl_down(fy, d), tz = __shfl_down(fz, d);
-               fx += take ? tx : R(0.0); fy += take ? ty : R(0.0); fz += take ? tz : R(0.0);
-               if (STEP == 1) { const real_t te = __shfl_down(e, d), tr = __shfl_down(rb, d); e += take ? te : R(0.0); rb += take ? tr : R(0.0); }
+               if (d < L) {                                   // (wave-uniform)
+                  const int from = ((lane + d) & 63) << 2;
+                  const real_t w = q + d < L ? R(1.0) : R(0.0);
+                  fx = fmaR(bpermuteAddrR(fx, from), w, fx); fy = fmaR(bpermuteAddrR(fy, from), w, fy); fz = fmaR(bpermuteAddrR(fz, from), w, fz);
+                  if (STEP == 1) { e = fmaR(bpermuteAddrR(e, from), w, e); rb = fmaR(bpermuteAddrR(rb, from), w, rb); }
+               }
             }
          }
-         const bool embedLane = have && q == 0;
-         const real_t eSum = e, rbs = rb;
-         if (have && q == 0) {
-            if (STEP == 1) { (a.fx + cellSlot)[ii] = fx; (a.fy + cellSlot)[ii] = fy; (a.fz + cellSlot)[ii] = fz; }
+         // Order of the memory operations at the end of a round: the table samples of the embedding (pass 2 for these atoms: EAM_Force_embed needs
+         // only the atom's own rhobar) are REQUESTED FIRST and every store comes after them -- loads and stores retire in issue order, and a load
+         // queued behind this round's stores would wait for their acknowledgements; the stores of the previous cell are a cell of arithmetic old.
+         const bool sumLane = have && q == 0;
+         real_t pR = R(0.0), pv0 = R(0.0), pv1 = R(0.0), pv2 = R(0.0), pv3 = R(0.0);
+         if (STEP == 1 && b.fuseEmbed && sumLane) {           // interpolate() split in two
+            real_t r = maxR(rb, a.f.x0);
+            r = minR(r, a.f.xn);
+            r = r * a.f.invDx - a.f.invDxXx0;
+            const real_t ri = floorR(r);
+            const int it = (int)ri;
+            pR = r - ri;
+            pv0 = a.f.values[it]; pv1 = a.f.values[it + 1]; pv2 = a.f.values[it + 2]; pv3 = a.f.values[it + 3];
+         }
+         if (STEP == 1) {
+            // hand the lane's words to pass 3 (the second 16 bytes only when a trip beyond the fourth was made), and the row lengths
+            if (have) {
+               uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG + cellSlot * EAM_ROW_WORDS) + ii * (EAM_ROW_WORDS / 4) + 2u * (unsigned)q;
+               if (q < nPairs) dst[0] = make_uint4(wReg[0], wReg[1], wReg[2], wReg[3]);
+               if (4 * L + q < nPairs) dst[1] = make_uint4(wReg[4], wReg[5], wReg[6], wReg[7]);
+            }
+            if (lane < nRound) (b.rowCountG + cellSlot)[(unsigned)(i0 + lane)] = (unsigned short)(sCnt[lane] < b.rows ? sCnt[lane] : b.rows);
+         }
+         if (sumLane) {
+            if (STEP == 1) { (a.fx + cellSlot)[ii] = fx; (a.fy + cellSlot)[ii] = fy; (a.fz + cellSlot)[ii] = fz; (a.rhobar + cellSlot)[ii] = rb; }
             else { (a.fx + cellSlot)[ii] = cur.f0x + fx; (a.fy + cellSlot)[ii] = cur.f0y + fy; (a.fz + cellSlot)[ii] = cur.f0z + fz; }
          }
-#endif
-         if (STEP == 1) {
-            finishEmbed();                                   // the previous round's atoms (their table samples were requested a round ago)
-            if (embedLane) {
-               (a.rhobar + cellSlot)[ii] = rbs;
-               if (b.fuseEmbed) {                             // pass 2 for this atom (EAM_Force_embed): needs only its own rhobar; split interpolate()
-                  real_t r = maxR(rbs, a.f.x0);
-                  r = minR(r, a.f.xn);
-                  r = r * a.f.invDx - a.f.invDxXx0;
-                  const real_t ri = floorR(r);
-                  const int it = (int)ri;
-                  pR = r - ri; pE = R(0.5) * eSum; pIo = cellSlot + ii; pend = true;
-                  pv0 = a.f.values[it]; pv1 = a.f.values[it + 1]; pv2 = a.f.values[it + 2]; pv3 = a.f.values[it + 3];
-               } else (a.e + cellSlot)[ii] = R(0.5) * eSum;
+         if (STEP == 1 && sumLane) {
+            real_t ei = R(0.5) * e;
+            if (b.fuseEmbed) {
+               const real_t g1 = pv2 - pv0, g2 = pv3 - pv1;
+               ei += pv1 + R(0.5) * pR * (g1 + pR * (pv2 + pv0 - R(2.0) * pv1));
+               (a.dfEmbed + cellSlot)[ii] = (g1 + pR * (g2 - g1)) * a.f.invDxHalf;
             }
+            (a.e + cellSlot)[ii] = ei;
          }
          __builtin_amdgcn_wave_barrier();
       }
    }
-   if (STEP == 1) finishEmbed();
    if (__builtin_amdgcn_ballot_w64(over) != 0ull && lane == 0) atomicOr(&b.status[3], 1);
 }

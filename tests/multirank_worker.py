@@ -138,6 +138,13 @@ def gpu_mode(pkg, orc, dist, rank, world, grid, eam, n, method, use_async, trans
     if rank == 0:
         o = orc.Oracle(n, grid, eam=eam, delta=0.1)
         fo, eo = o.gather(orc.F), o.energy()
+        err = np.abs(f0 - fo).max(axis=1)
+        if err.max() >= TOL["force_rel_to_max"] * np.abs(fo).max():      # say where before failing: the worst atoms and where they sit
+            worst = np.argsort(err)[-8:][::-1]
+            r0 = o.gather(orc.R)
+            print("force mismatch at step 0: %d atoms off by more than the tolerance; worst:" % int((err >= TOL["force_rel_to_max"] * np.abs(fo).max()).sum()))
+            for g in worst:
+                print("  gid %6d  |df| %.3e  r = (%.3f, %.3f, %.3f)  f = %s  oracle %s" % (g, err[g], *r0[g], f0[g], fo[g]))
         assert np.abs(f0 - fo).max() < TOL["force_rel_to_max"] * np.abs(fo).max()
         assert abs(e0[0] - eo[0]) / e0[2] < TOL["energy_per_atom_step0"] and abs(e0[1] - eo[1]) / e0[2] < 10 * TOL["kinetic_per_atom"]
         o.step(steps)

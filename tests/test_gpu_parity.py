@@ -145,7 +145,9 @@ def test_lj_wave_candidate_lists_and_their_fallbacks(gpu, orc, monkeypatch, env)
 @pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("case", ["eam_6_delta", "lj_8_delta"])
 def test_reference_recorded_forces(gpu, case, method):
-    """The -r 0.1 known answers recorded from the unmodified reference."""
+    """SECONDARY cross-check: the -r 0.1 force statistics of reference_values.json "survey_recorded" were written down by the survey stage from a
+    stub-header build that nothing here regenerates; they pin nothing by themselves.  What ties the forces to the reference is
+    tests/test_finite_difference.py: F = -dU/dr of the energies pinned to CoMD.c:897-899."""
     ref = S[case]
     with gpu.Simulation(_args(ref["nx"], ref["eam"], ref["delta"], method)) as sim:
         _, u, _ = _per_atom(sim)

@@ -10,8 +10,16 @@ import numpy as np
 import pytest
 
 G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_values.json")))
-TOL = G["tolerances"]
+# COMD_PRECISION=single (tests/test_single_precision.py runs the repo_native tests of this file in a child): the checker built with real_t = float is
+# held to the same reference-held values at the float tolerances ("tolerances_single"), on boxes small enough that the sequential float sum of the
+# per-atom energies (the reference's own, timestep.c:109-133) is not what is being measured
+SINGLE = os.environ.get("COMD_PRECISION", "double") == "single"
+TOL = G["tolerances_single" if SINGLE else "tolerances"]
 S = G["survey_recorded"]
+
+
+def _fixture_tol(ref):
+    return max(ref["tolerance"], TOL["energy_per_atom_step0"]) if SINGLE else ref["tolerance"]
 
 
 def per_atom(o):
@@ -35,20 +43,20 @@ def test_lj_cohesive_energy_repo_native(orc):
     o = orc.Oracle(10, eam=0, temperature=0.0, lj_cutoff_sigmas=2.5)
     _, u, k = per_atom(o)
     assert k == 0.0
-    assert abs(u - ref["value"]) < ref["tolerance"]
-    assert np.abs(o.gather(orc.F)).max() < 1e-12                  # perfect lattice: every force is a sum that cancels
+    assert abs(u - ref["value"]) < _fixture_tol(ref)
+    assert np.abs(o.gather(orc.F)).max() < (1e-4 if SINGLE else 1e-12)      # perfect lattice: every force is a sum that cancels (float: ~550 terms of O(1) at 6e-8 each)
     # and on 2x2x2 virtual ranks (decomposition independence at the shorter cutoff too)
     o8 = orc.Oracle(12, (2, 2, 2), eam=0, temperature=0.0, lj_cutoff_sigmas=2.5)
-    assert abs(per_atom(o8)[1] - ref["value"]) < ref["tolerance"]
+    assert abs(per_atom(o8)[1] - ref["value"]) < _fixture_tol(ref)
 
 
 def test_eam_step0_row_of_k20_log(orc):
     """Step-0 row of out16_80_3.txt: U and K per atom do not depend on the lattice size for a perfect lattice at exactly 600 K."""
     ref = G["repo_native"]["eam_80_step0_gpu_log"]
-    o = orc.Oracle(20, eam=1)
+    o = orc.Oracle(6 if SINGLE else 20, eam=1)      # (float: the sequential sum of 6912 per-atom energies is already 3e-4 eV/atom off)
     e, u, k = per_atom(o)
     assert abs(u - ref["U"]) < TOL["energy_per_atom_step0"]
-    assert abs(k - ref["K"]) < 1e-11      # exact rescale to T = 600 K: K = 1.5 kB T
+    assert abs(k - ref["K"]) < (TOL["kinetic_per_atom"] if SINGLE else 1e-11)      # exact rescale to T = 600 K: K = 1.5 kB T
     assert abs(e - ref["E"]) < TOL["energy_per_atom_step0"]
 
 
@@ -143,4 +151,4 @@ def test_setfl_mishin_cohesive_energy(orc):
     o = orc.Oracle(8, eam=1, temperature=0.0, pot_name="Cu01.eam.alloy")
     ep, ek = o.energy()
     assert ek == 0.0
-    assert abs(ep / o.n_global - ref["value"]) < ref["tolerance"]
+    assert abs(ep / o.n_global - ref["value"]) < _fixture_tol(ref)

@@ -41,6 +41,13 @@ def test_single_precision_host_logic_is_bit_exact_against_the_checker():
     assert "passed" in out
 
 
+def test_single_precision_checker_meets_the_reference_held_energies():
+    """liboracle_sp.so itself against the values the reference holds (CoMD.c:897-899, the step-0 row of the K20 log), at the float tolerances:
+    the float checker is pinned by more than being the same source as the double one."""
+    out = _run(["tests/test_oracle_golden.py"], "repo_native or step0_row_of_k20_log or setfl_mishin_cohesive_energy", "not gpu", 600)
+    assert "4 passed" in out, out[-800:]
+
+
 @pytest.mark.gpu
 def test_single_precision_gpu_parity():
     """Forces, energies, densities, redistribution, lists, pairlists, setfl tables and reproducibility of the float kernels on the GPU."""
