@@ -143,7 +143,15 @@ extern "C" void comdMemcpyAsync(void* dst, const void* src, long bytes, int kind
    const hipMemcpyKind k = kind == 1 ? hipMemcpyHostToDevice : kind == 2 ? hipMemcpyDeviceToHost : kind == 3 ? hipMemcpyDeviceToDevice : hipMemcpyHostToHost;
    HIP_CHECK(hipMemcpyAsync(dst, src, (size_t)bytes, k, S(stream)));
 }
-extern "C" void comdDeviceMemset(void* p, int value, long bytes) { if (bytes > 0) HIP_CHECK(hipMemset(p, value, (size_t)bytes)); }
+// cudaMemset of the reference's host files (timestep.c:224): issued on the legacy default stream, which waits for and is waited for by the reference's
+// streams (created with flags 0, gpu_utility.c:150-152).  The -a 1 streams here are non-blocking, so the same ordering is spelled out.
+extern "C" void comdDeviceMemset(void* p, int value, long bytes)
+{
+   if (bytes <= 0) return;
+   HIP_CHECK(hipDeviceSynchronize());
+   HIP_CHECK(hipMemset(p, value, (size_t)bytes));
+   HIP_CHECK(hipDeviceSynchronize());
+}
 
 template <typename T> static T* dalloc(size_t n, bool zero = true)
 {
@@ -361,7 +369,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
-                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1] };
+                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1] };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));

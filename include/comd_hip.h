@@ -172,6 +172,10 @@ typedef struct SimGpu {
    int          fuseEmbed;             /* host switch, default 0: with method CTA_CELL eamForce1Gpu[Async] also does the work of eamForce2Gpu[Async] for the
                                         * cells it covers (F(rhobar), F'(rhobar) need nothing but the atom's own rhobar) and eamForce2Gpu[Async] returns at
                                         * once -- same e[], dfEmbed[] after the pair of calls, one launch fewer */
+   /* scan scratch of the reference-side adapter (include/comd_hip_shim.h comdShimOffsets): the reference's per-face partial_sums arrays hold nCells ints,
+    * the scans here need nCells + 1; grown on demand, freed by DestroyGpu; the library itself never touches it */
+   int*         adapterScan;
+   int          adapterScanCap;
    /* fields the reference's host code assigns (timestep.c:229-236); kept so that those statements compile, not read by the library */
    HashTableGpu d_hashTable;
    int          genPairlist;

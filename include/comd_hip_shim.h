@@ -8,8 +8,8 @@
  * reference signature carries host staging (the reference packs on the device, copies to a pinned host buffer and sends that
  * with MPI; libcomd_hip keeps messages on the device, so the adapters add the copy the call site expects).
  *
- * Compiled and linked by tests/test_boundary_shim.py (gcc, -Wall -Werror) against a mirror of the reference's SimFlat fields;
- * nothing in the product includes this file.
+ * Compiled and linked by tests/test_boundary_shim.py (gcc, -Wall -Werror) against a mirror of the reference's SimFlat fields, and RUN on the GPU by the
+ * same file (tests/shim/shim_driver.c drives whole time steps through these adapters); nothing in the product includes this file.
  *
  * Function-like macros with the name of the function they wrap are deliberate: inside its own expansion a macro name is not
  * expanded again, and `(name)(...)` always reaches the real function.
@@ -57,7 +57,9 @@ typedef real_t real3_old[3];
 #define computeEnergy(sim, eLocal) (computeEnergy)(&(sim)->gpu, (eLocal))                           /* timestep.c:188 */
 
 /* ---- redistribute: gpu_kernels.h:84-86.  The reference keeps its streams in SimFlat (CoMDTypes.h:116-117) -------------- */
-#define updateLinkCellsGpu(sim)       (updateLinkCellsGpu)(&(sim)->gpu, (sim)->boundary_stream)     /* timestep.c:234, 246 */
+/* the reference's updateLinkCellsGpu returns after a blocking device read (gpu_kernels.cu:497), and its callers rely on that: timestep.c:257-265 starts
+ * the interior cells' force work on ANOTHER stream right after it.  The library's call only enqueues, so the adapter adds the wait. */
+#define updateLinkCellsGpu(sim)       ((updateLinkCellsGpu)(&(sim)->gpu, (sim)->boundary_stream), comdStreamSynchronize((sim)->boundary_stream))     /* timestep.c:234, 246 */
 #define buildAtomListGpu(sim, stream) (buildAtomListGpu)(&(sim)->gpu, (stream))                     /* timestep.c:244, 271 */
 #define sortAtomsGpu(sim, stream)     (sortAtomsGpu)(&(sim)->gpu, (stream))                         /* timestep.c:248, 274 */
 
@@ -69,17 +71,16 @@ typedef real_t real3_old[3];
 static inline char* comdShimAtomsBufAlloc(long payloadBytes) { return (char*)comdDeviceMalloc(payloadBytes + COMD_ATOM_MSG_HEADER) + COMD_ATOM_MSG_HEADER; }
 static inline void  comdShimAtomsBufFree(char* p) { if (p) comdDeviceFree(p - COMD_ATOM_MSG_HEADER); }
 
-/* scan scratch of nCells + 1 ints (the reference's partial_sums arrays hold nCells): grown on demand, one per process */
-static inline int* comdShimOffsets(int nCells)
+/* scan scratch of nCells + 1 ints (the reference's partial_sums arrays hold nCells): grown on demand, kept in the SimGpu it serves
+ * (SimGpu.adapterScan; two simulations on two devices never share it), freed by DestroyGpu */
+static inline int* comdShimOffsets(SimGpu* gpu, int nCells)
 {
-   static int* scratch = 0;
-   static int  capacity = 0;
-   if (nCells + 1 > capacity) {
-      if (scratch) comdDeviceFree(scratch);
-      capacity = 2 * (nCells + 1);
-      scratch = (int*)comdDeviceMalloc((long)capacity * (long)sizeof(int));
+   if (nCells + 1 > gpu->adapterScanCap) {
+      if (gpu->adapterScan) comdDeviceFree(gpu->adapterScan);
+      gpu->adapterScanCap = 2 * (nCells + 1);
+      gpu->adapterScan = (int*)comdDeviceMalloc((long)gpu->adapterScanCap * (long)sizeof(int));
    }
-   return scratch;
+   return gpu->adapterScan;
 }
 
 /* int compactCellsGpu(work_d, nCells, d_cellList, SimGpu, d_cellOffsets, d_workScan, shift, stream), gpu_kernels.cu:519-551:
@@ -88,7 +89,7 @@ static inline int comdShimCompactCells(char* work_d, int nCells, int* d_cellList
 {
    (void)d_cellOffsets;                                  /* nCells ints in the reference; the scan here needs nCells + 1 */
    char* msg = work_d - COMD_ATOM_MSG_HEADER;
-   compactCellsGpu(msg, nCells, d_cellList, gpu, comdShimOffsets(nCells), shift, INT_MAX, stream);
+   compactCellsGpu(msg, nCells, d_cellList, gpu, comdShimOffsets(gpu, nCells), shift, INT_MAX, stream);
    return atomMsgCountGpu(gpu, msg, stream);
 }
 #define compactCellsGpu(work_d, nCells, d_cellList, g, d_cellOffsets, d_workScan, shift, stream) \
@@ -106,7 +107,7 @@ static inline void comdShimUnloadAtoms(const char* hostBuf, int nBuf, SimGpu* gp
 /* void loadForceBufferFromGpu(buf (host), &nBuf, nCells, cellList, natoms_buf, partial_sums, SimFlat*, gpu_buf, stream), :619-640 */
 static inline void comdShimLoadForce(char* hostBuf, int* nBuf, int nCells, int* d_cellList, SimGpu* gpu, char* gpu_buf, comdStream_t stream)
 {
-   int* off = comdShimOffsets(nCells);
+   int* off = comdShimOffsets(gpu, nCells);
    loadForceBufferFromGpu((real_t*)gpu_buf, nCells, d_cellList, off, gpu, stream);
    *nBuf = comdReadDeviceInt(off + nCells, stream);
    comdMemcpyAsync(hostBuf, gpu_buf, (long)*nBuf * (long)sizeof(real_t), cudaMemcpyDeviceToHost, stream);
@@ -119,7 +120,7 @@ static inline void comdShimLoadForce(char* hostBuf, int* nBuf, int nCells, int* 
 static inline void comdShimUnloadForce(const char* hostBuf, int nBuf, int nCells, int* d_cellList, SimGpu* gpu, char* gpu_buf, comdStream_t stream)
 {
    comdMemcpyAsync(gpu_buf, hostBuf, (long)nBuf * (long)sizeof(real_t), cudaMemcpyHostToDevice, stream);
-   unloadForceBufferToGpu((const real_t*)gpu_buf, nCells, d_cellList, comdShimOffsets(nCells), gpu, stream);
+   unloadForceBufferToGpu((const real_t*)gpu_buf, nCells, d_cellList, comdShimOffsets(gpu, nCells), gpu, stream);
 }
 #define unloadForceBufferToGpu(buf, nBuf, nCells, cellList, natoms_buf, partial_sums, s, gpu_buf, stream) \
    comdShimUnloadForce((buf), (nBuf), (nCells), (cellList), &(s)->gpu, (gpu_buf), (stream))             /* haloExchange.c:1885 */

@@ -1,4 +1,4 @@
-/* reference_callsites.c -- TEST INFRASTRUCTURE (tests/test_boundary_shim.py compiles and links it; it is never run).
+/* reference_callsites.c -- TEST INFRASTRUCTURE (tests/test_boundary_shim.py compiles and links it, and runs it on the GPU through shim_driver.c).
  *
  * The drop-in claim of include/comd_hip_shim.h, put through a compiler: every device-library call expression of the reference's
  * hot-path host files, written here AS THE REFERENCE WRITES IT (argument for argument; the file:line each one comes from is in the
@@ -22,6 +22,11 @@ typedef struct SimFlatSt {
    int* flags;
    char *gpu_atoms_buf, *gpu_force_buf;
    comdStream_t boundary_stream, interior_stream;      /* cudaStream_t in the reference (CoMDTypes.h:116-117) */
+   /* scaffolding: where the reference calls haloExchange(sim->atomExchange, sim) (timestep.c:269) and haloExchange(pot->forceExchange, s) (eam.c:241) --
+    * host code of the reference, not a device-library call -- the driver hooks its own exchange loop built from the four pack/unpack scaffolds below */
+   void (*atomHalo)(struct SimFlatSt*);
+   void (*forceHalo)(struct SimFlatSt*);
+   void* world;
 } SimFlat;
 typedef struct { int nCells[6]; int* cellListGpu[6]; int *d_natoms_buf, *d_partial_sums; } AtomExchangeParms;
 typedef struct { int nCells[6]; int *sendCellsGpu[6], *recvCellsGpu[6], *natoms_buf[6], *partial_sums[6]; } ForceExchangeParms;
@@ -53,6 +58,7 @@ int shim_eamForceGpu(SimFlat* s)
          eamForce2Gpu(s->gpu,s->method, s->spline);                                                                                        /* eam.c:235 */
    }
    if (!s->gpuProfile) {
+      if (s->forceHalo) s->forceHalo(s);                                                                                                   /* eam.c:241 haloExchange(pot->forceExchange, s) */
       if (s->gpuAsync) {
          cudaStreamSynchronize(s->boundary_stream);                                                                                        /* eam.c:250 */
          eamForce3GpuAsync(s->gpu, s->gpu.b_list, s->n_boundary_cells, s->boundary_cells, s->method, s->boundary_stream, s->spline);       /* eam.c:255 */
@@ -69,6 +75,9 @@ void shim_advance(SimFlat* s, real_t dt)
    advanceVelocityGpu(s->gpu, dt);                       /* timestep.c:138 */
    advancePositionGpu(&(s->gpu), dt);                    /* timestep.c:158 */
 }
+
+void shim_advanceVelocity(SimFlat* s, real_t dt) { advanceVelocityGpu(s->gpu, dt); }        /* timestep.c:137-141 */
+void shim_advancePosition(SimFlat* s, real_t dt) { advancePositionGpu(&(s->gpu), dt); }     /* timestep.c:156-160 */
 
 void shim_kineticEnergyGpu(SimFlat* s, real_t eLocal[2])
 {
@@ -99,6 +108,7 @@ void shim_redistributeAtomsGpu(SimFlat* sim)
       eamForce1GpuAsync(sim->gpu, sim->gpu.i_list, n_interior_cells, sim->interior_cells, sim->method, sim->interior_stream, sim->spline); /* timestep.c:263 */
       eamForce2GpuAsync(sim->gpu, sim->gpu.i_list, n_interior_cells, sim->interior_cells, sim->method, sim->interior_stream, sim->spline); /* timestep.c:264 */
    }
+   if (sim->atomHalo) sim->atomHalo(sim);                                                                                                  /* timestep.c:269 haloExchange(sim->atomExchange, sim) */
    buildAtomListGpu(sim, sim->boundary_stream);                                                                                            /* timestep.c:272 */
    sortAtomsGpu(sim, sim->boundary_stream);                                                                                                /* timestep.c:275 */
 }

@@ -83,3 +83,82 @@ def test_reference_call_expressions_compile_and_link(tmp_path):
     undefined = {line.split()[-1] for line in syms.splitlines() if " U " in line}
     assert {"ljForceGpu", "eamForce1GpuAsync", "eamForce3Gpu", "advanceVelocityGpu", "advancePositionGpu", "computeEnergy", "updateLinkCellsGpu", "sortAtomsGpu",
             "compactCellsGpu", "unloadAtomsBufferToGpu", "loadForceBufferFromGpu", "unloadForceBufferToGpu", "pairlistUpdateRequiredGpu"} <= undefined
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The adapter EXECUTED: whole time steps of a live simulation through the reference's call expressions (tests/shim/shim_driver.c).
+class _ShimWorld(ctypes.Structure):
+    _fields_ = [("nAtomCells", ctypes.c_int * 6), ("atomCells", ctypes.c_void_p * 6),
+                ("nForceCells", ctypes.c_int * 6), ("forceSend", ctypes.c_void_p * 6), ("forceRecv", ctypes.c_void_p * 6),
+                ("shift", (ctypes.c_double * 3) * 6),
+                ("nLocalBoxes", ctypes.c_int), ("nTotalBoxes", ctypes.c_int), ("method", ctypes.c_int), ("eam", ctypes.c_int), ("gpuAsync", ctypes.c_int),
+                ("cutoff", ctypes.c_double),
+                ("_driver_private", ctypes.c_byte * 1024)]      # AtomExchangeParms, ForceExchangeParms, host buffers: filled by the driver
+
+
+def _build_driver(tmp_path):
+    so = str(tmp_path / "libshim_driver.so")
+    cmd = ["gcc", "-std=gnu11", "-O1", "-fPIC", "-shared", "-Wall", "-Wextra", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "shim"),
+           os.path.join(ROOT, "tests", "shim", "shim_driver.c"), "-o", so, "-L" + CSRC, "-lcomd_hip", "-Wl,--no-undefined", "-Wl,-rpath," + CSRC]
+    cc = subprocess.run(cmd, capture_output=True, text=True)
+    assert cc.returncode == 0, cc.stderr[-4000:]
+    return ctypes.CDLL(so)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(shutil.which("gcc") is None, reason="gcc not on PATH")
+@pytest.mark.parametrize("eam,method,use_async,n", [(0, "thread_atom", 0, 10), (0, "cta_cell", 0, 10), (1, "cta_cell", 0, 8), (1, "cta_cell", 1, 10), (1, "thread_atom", 1, 10)])
+def test_reference_side_adapter_drives_whole_time_steps(gpu, orc, tmp_path, eam, method, use_async, n):
+    """Twelve velocity-Verlet steps of a hot, displaced lattice driven ENTIRELY through include/comd_hip_shim.h: shim_advanceVelocity/Position,
+    shim_redistributeAtomsGpu, shim_ljForce / shim_eamForceGpu (both gpuAsync branches), shim_kineticEnergyGpu, and the atom and dF/drho halo
+    exchanges through the four host-staged pack/unpack adapters (self-exchange through host buffers, parallel.c:112-117).  Energies, forces and
+    positions against the oracle at the usual tolerances; atoms must migrate between cells and through the periodic faces on the way."""
+    import json
+    import numpy as np
+    G = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_values.json")))
+    single = os.environ.get("COMD_PRECISION", "double") == "single"
+    tol = G["tolerances_single" if single else "tolerances"]
+    drv = _build_driver(tmp_path)
+    methods = {"thread_atom": 0, "cta_cell": 4}                                   # comd_hip.h: THREAD_ATOM, CTA_CELL
+    args = ["-x", n, "-y", n, "-z", n, "-r", 0.3, "-T", 4000, "-m", method, "-a", use_async] + (["-e"] if eam else [])
+    with gpu.Simulation(args) as sim:
+        o = orc.Oracle(n, eam=eam, delta=0.3, temperature=4000.0, cap=max(sim.max_atoms, 64))
+        w = _ShimWorld()
+        keep = []
+        for f in range(6):
+            a = np.ascontiguousarray(sim.face_cells(0, f), dtype=np.int32)
+            s_ = np.ascontiguousarray(sim.face_cells(1, f), dtype=np.int32)
+            r_ = np.ascontiguousarray(sim.face_cells(2, f), dtype=np.int32)
+            keep += [a, s_, r_]
+            w.nAtomCells[f], w.atomCells[f] = len(a), a.ctypes.data
+            w.nForceCells[f], w.forceSend[f], w.forceRecv[f] = len(s_), s_.ctypes.data, r_.ctypes.data
+            assert len(s_) == len(r_)
+            v = (ctypes.c_double * 3)()
+            sim.lib.comdFaceShift(sim.ptr, f, v)
+            for c in range(3):
+                w.shift[f][c] = v[c]
+        w.nLocalBoxes, w.nTotalBoxes, w.method, w.eam, w.gpuAsync = sim.n_local_boxes, sim.n_total_boxes, methods[method], eam, use_async
+        w.cutoff = o.L.oracle_cutoff(o.ptr)
+        e = (ctypes.c_double * 2)()
+        drv.shim_world_run.argtypes = [ctypes.c_void_p, ctypes.POINTER(_ShimWorld), ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_double)]
+        oc0 = o.rank_cells(0)
+        drv.shim_world_run(ctypes.c_void_p(sim.lib.comdSimGpu(sim.ptr)), ctypes.byref(w), 12, 1.0, e)
+        o.step(12)
+        ep, ek = o.energy()
+        ng = sim.n_global
+        assert abs(e[0] - ep) / ng < 10 * tol["energy_per_atom_trace"] and abs(e[1] - ek) / ng < 10 * tol["energy_per_atom_trace"]
+        fo, ro = o.gather(orc.F), o.gather(orc.R)
+        assert np.abs(sim.gather(2) - fo).max() <= 100 * tol["force_rel_to_max"] * np.abs(fo).max()      # (twelve steps of round-off growth, as in the trajectory tests)
+        ext = n * 3.615
+        d = sim.gather(0) - ro
+        d -= np.rint(d / ext) * ext
+        assert np.abs(d).max() < (1e-4 if single else 1e-10)
+        # cell membership, local AND halo, is the oracle's -- in gid order, as the dF/drho exchange needs it -- and it is not the initial one: the
+        # re-binning, the migration through the periodic faces and the exchange had work to do
+        c, oc = sim.cells(), o.rank_cells(0)
+        assert np.array_equal(c["nAtoms"], oc["nAtoms"])
+        for b in range(sim.n_total_boxes):
+            k = c["nAtoms"][b]
+            assert np.array_equal(c["gid"][b, :k], oc["gid"][b, :k]), b
+        moved = sum(1 for b in range(sim.n_local_boxes) if oc["nAtoms"][b] != oc0["nAtoms"][b] or not np.array_equal(oc["gid"][b, :oc["nAtoms"][b]], oc0["gid"][b, :oc0["nAtoms"][b]]))
+        assert moved > 0
