@@ -18,6 +18,14 @@ Extra objects on the JSON line:
                  workload (same potential, same density, fewer atoms and steps), rank 0 at N = 1 only.
   variants     : N = 1 only: the same K timed steps with the other force methods (cta_cell, the Verlet-list method
                  thread_atom_nl) and the other potential, for comparison; `value` is always the named configuration.
+                 The BASELINE.json configurations among them (EAM 80^3 cta_cell = configs[2]) carry a `roofline` object of their own.
+  target_line  : N = 1 only: BASELINE.json's north_star line, LJ 256^3 (67 M atoms) thread_atom, 3 timed steps after 1 -- value, ms/step,
+                 kernel and whole-evaluation ms, HBM and fp64 fractions, memory of the candidate lists; skipped with a stated reason when
+                 the device has less than 60 GB free.
+
+N > 1: the ranks form their RCCL communicator the way comd-hip does (comdCommInitFromEnv: RANK / WORLD_SIZE / LOCAL_RANK from the launcher, rendezvous
+through a file keyed by the launcher's pid and restart count); the two collectives the harness needs (barrier, max of the elapsed times) go through
+CommTransport.  No torch in the rank processes: libcomd_hip.so runs on the one HIP runtime and the one librccl it was linked against (/opt/rocm).
 """
 import argparse
 import json
@@ -42,6 +50,7 @@ FORCE_FLOP = {"lj": 4000 * 8 + 550 * 25, "eam": 2 * (283 * 8 + 42 * 70)}
 FORCE_FLOP_LISTED = {"lj": 2350 * 8 + 550 * 25}
 # Verlet lists (skin 10 %): ~732 (LJ) / ~57 (EAM) listed neighbours take the place of the stencil candidates
 FORCE_FLOP_NL = {"lj": 732 * 8 + 550 * 25, "eam": 2 * (57 * 8 + 42 * 70)}
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0                 # wave-instructions/s the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction
 KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs", ("lj", "cta_cell_pairlist"): "LJ_Force_cta_cell",
                ("eam", "thread_atom"): "EAM_Force_thread_atom", ("eam", "cta_cell"): "EAM_Force_cta_cell", ("eam", "thread_atom_nl"): "EAM_Force_nl_lds"}
 
@@ -58,6 +67,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true", help="skip the other force methods (reported as `variants` at N = 1)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--no-target-line", action="store_true", help="skip the LJ 256^3 leg (N = 1 default run)")
     ap.add_argument("--precision", choices=["double", "single"], default="double",
                     help="single: the PRECISION=single build (real_t = float); never the headline -- the default run reports it as a variant")
     ap.add_argument("--allow-host-staged", action="store_true",
@@ -112,20 +122,45 @@ def cpu_baseline(pot, seconds):
                          "sample": f"same workload, {steps1} steps, 1 thread (the reference runs one thread per rank), {loop1:.1f} s"}}
 
 
-def measured_traffic(pot, method, nx):
-    """HBM-side bytes per force evaluation from the committed rocprofv3 PMC passes (profiles/r02_traffic.json), or None.
-    PMC counters cannot be read from inside the timed process, so the last profiled value for this workload is reported."""
-    rec = None
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+def profiled(pot, method, nx):
+    """The committed rocprofv3 PMC passes for this workload (profiles/rNN_traffic.json, newest round first): HBM-side bytes (FETCH_SIZE + WRITE_SIZE) and VALU
+    wave-instructions per force evaluation.  PMC counters cannot be read from inside the timed process, so these are the last profiled values, and the
+    record says which file they come from."""
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name))).get(f"{pot}/{method}/{nx}")
         except (OSError, ValueError):
             rec = None
         if rec:
-            break
-    if not rec:
-        return None
-    return (rec["fetch_KiB"] + rec["write_KiB"]) * 1024.0
+            return rec, f"profiles/{name}"
+    return None, None
+
+
+def roofline_object(pot, method, nx, n_local, force_ms, aux_ms, precision, one_gpu=True):
+    """`roofline` of one force path: algorithmic bytes / live kernel time against the HBM roof, the fp64 (fp32) vector ceiling beside it, the
+    cost of a whole force evaluation (kernel + list build), and the counter-derived figures of the committed PMC passes with their provenance."""
+    flop = (FORCE_FLOP_NL if method.endswith("_nl") else FORCE_FLOP)[pot]
+    if pot == "lj" and method == "thread_atom" and os.environ.get("COMD_LJ_PRUNE", "1") != "0":
+        flop = FORCE_FLOP_LISTED["lj"]
+    achieved = FORCE_BYTES[pot] * n_local / (force_ms * 1e-3) / 1e9 if force_ms > 0 else None
+    rec, prov = profiled(pot, method, nx) if one_gpu else (None, None)
+    vec = "fp64_vector" if precision == "double" else "fp32_vector"
+    out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
+           "traffic": (rec["fetch_KiB"] + rec["write_KiB"]) * 1024.0 if rec and precision == "double" else None,
+           "traffic_provenance": (f"{prov}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw counter values summed over the launches of one force "
+                                  "evaluation -- a stored value, not this run's") if rec and precision == "double" else None,
+           "kernel": KERNEL_NAME[(pot, method)], "kernel_ms_per_step": force_ms,
+           "force_evaluation_ms": force_ms + aux_ms,      # every launch of one force call: the kernel(s) + list build / cell marks
+           "algorithmic_bytes_per_atom": FORCE_BYTES[pot],
+           vec: {"achieved_TFLOPs": flop * n_local / (force_ms * 1e-3) / 1e12 if force_ms > 0 else None, "peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "flop_per_atom": flop,
+                 "frac": flop * n_local / (force_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if force_ms > 0 else None,
+                 "note": "a FLOP MODEL (constants at the top of bench.py), not a counter"}}
+    if rec and precision == "double" and rec.get("insts_valu") and force_ms > 0:
+        rate = rec["insts_valu"] / (force_ms * 1e-3)
+        out["valu_issue_frac"] = rate / VALU_ISSUE_PEAK
+        out["valu_issue_provenance"] = (f"{prov}: SQ_INSTS_VALU of the force kernel(s) per evaluation ({rec['insts_valu']:.4g}) / this run's kernel time, against "
+                                        f"{VALU_ISSUE_PEAK:.3g} wave-instructions/s (256 CUs x 4 SIMDs x 2.4 GHz / 4)")
+    return out
 
 
 def main():
@@ -149,110 +184,129 @@ def main():
     px, py, pz = GRIDS[a.gpus]
     use_async = a.async_halo if a.async_halo is not None else (1 if a.gpus > 1 else 0)
 
+    import ctypes
     # One GPU can rehearse the multi-GPU code path: COMD_LOOPBACK_TRANSPORT=1 sends every halo message and reduction of the
-    # single rank through RCCL (to itself), with the same library load order and rendezvous as a torch.distributed.run launch.
+    # single rank through RCCL (to itself), with the same bootstrap as a torch.distributed.run launch.
     loopback = world == 1 and os.environ.get("COMD_LOOPBACK_TRANSPORT", "0") not in ("", "0")
     transport_name = None
     rccl_info = None
-    dist = None
-    if world > 1 or loopback:
-        import torch.distributed as dist                    # torch first: its bundled HIP/RCCL runtime is the one both sides share
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        with stdout_to_stderr():                           # gloo announces its peers on stdout
-            dist.init_process_group("gloo", rank=rank, world_size=world)   # control plane only; halo data moves over RCCL
+    transport = None
+    dist = None                                              # torch.distributed: only on the explicit --allow-host-staged path
     pkg = ge.load_package()
+    hip = pkg.lib_hip()
     if "COMD_FORCE_DEVICE" in os.environ:               # debugging aid: several ranks on one GPU
         local_rank = int(os.environ["COMD_FORCE_DEVICE"])
-    pkg.setup_gpu(local_rank, rank, verbose=False)         # stdout carries exactly one line: the JSON
-    if dist is not None:
-        with stdout_to_stderr():
-            ids = [pkg.rccl_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(ids, src=0)
-        import torch
-        try:
-            with stdout_to_stderr():
-                transport = pkg.rccl_transport(rank, world, ids[0])
-            ok = 1
-        except RuntimeError:
-            ok = 0
-        flag = torch.tensor([ok])
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)          # all ranks agree on the transport
-        if int(flag[0]) == 1:
+
+    def refuse():
+        # a SCALE record must never be produced over host-staged messages by accident
+        if rank == 0:
+            sys.stderr.write("bench.py: the RCCL communicator could not be formed on every rank; refusing to fall back to host-staged "
+                             "gloo messages (pass --allow-host-staged for a functional rehearsal)\n")
+        sys.exit(3)
+
+    if world > 1 or loopback:
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1"); os.environ.setdefault("LOCAL_RANK", "0")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        have_gpu = hip.comdDeviceCount() > local_rank
+        if have_gpu:
+            pkg.setup_gpu(local_rank, rank, verbose=False)     # stdout carries exactly one line: the JSON
+            with stdout_to_stderr():                           # RCCL announces itself on stdout
+                transport = pkg.rccl_transport_from_env()
+        if transport is not None:
             pkg.init_parallel(rank, world, transport)
-            # what the communicator itself says: N ranks, one device each, and which librccl this process runs
+            # what the communicator itself says: N ranks, one device each -- and which librccl / libamdhip64 this process runs (ONE of each: no torch
+            # in the process, so the copies libcomd_hip.so was linked against, /opt/rocm's)
             n_comm, r_comm, dev = pkg.rccl_comm_info()
-            mine = {"rank": r_comm, "device": dev, "librccl": pkg.mapped_libraries("librccl"), "libamdhip64": pkg.mapped_libraries("libamdhip64")}
-            gathered = [None] * world
-            dist.all_gather_object(gathered, mine)
-            rccl_info = {"rccl_ranks": n_comm, "rank_devices": [g["device"] for g in gathered],
-                         "librccl": sorted({p for g in gathered for p in g["librccl"]}),
-                         "libamdhip64": sorted({p for g in gathered for p in g["libamdhip64"]})}
             if n_comm != world:
                 sys.exit(f"bench.py: the RCCL communicator reports {n_comm} ranks, launched with {world}")
+            devs = (ctypes.c_int * world)()
+            devs[rank] = dev + 1
+            transport.allreduce(transport.ctx, ctypes.cast(devs, ctypes.c_void_p), world, 0)
+            libs = {"librccl": pkg.mapped_libraries("librccl"), "libamdhip64": pkg.mapped_libraries("libamdhip64")}
+            foreign = ctypes.c_int(0 if all(len(v) == 1 and os.path.realpath(v[0]).startswith("/opt/rocm") for v in libs.values()) else 1)
+            transport.allreduce(transport.ctx, ctypes.cast(ctypes.byref(foreign), ctypes.c_void_p), 1, 2)      # max over the ranks
+            rccl_info = {"rccl_ranks": n_comm, "rank_devices": [d - 1 for d in devs], "librccl": libs["librccl"], "libamdhip64": libs["libamdhip64"],
+                         "one_rocm_runtime_on_every_rank": foreign.value == 0}
+            assert foreign.value == 0 or "COMD_ALLOW_FOREIGN_RUNTIME" in os.environ, f"a HIP runtime or RCCL outside /opt/rocm is mapped: {libs}"
         elif not a.allow_host_staged:
-            # a SCALE record must never be produced over host-staged messages by accident
-            if rank == 0:
-                sys.stderr.write("bench.py: the RCCL communicator could not be formed on every rank; refusing to fall back to host-staged "
-                                 "gloo messages (pass --allow-host-staged for a functional rehearsal)\n")
-            dist.barrier()
-            sys.exit(3)
+            refuse()
         else:                                                # explicit opt-in: host-staged messages over gloo, marked as not measured
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            with stdout_to_stderr():
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            if not have_gpu:
+                sys.exit("bench.py: no HIP device visible (the product path has no CPU fallback)")
             transport_name = "gloo-host-staged (RCCL communicator could not be formed)"
             gloo = pkg.GlooTransport(dist)
             pkg.init_parallel(rank, world, gloo.struct)
     else:
+        pkg.setup_gpu(local_rank, rank, verbose=False)
         pkg.init_parallel(0, 1, None)
 
-    def measure(pot, meth, steps, warmup):
+    def barrier():
+        if transport is not None:
+            transport.barrier(transport.ctx)
+        elif dist is not None:
+            dist.barrier()
+
+    def max_over_ranks(seconds):
+        if transport is not None:
+            us = ctypes.c_int(int(seconds * 1e6))
+            transport.allreduce(transport.ctx, ctypes.cast(ctypes.byref(us), ctypes.c_void_p), 1, 2)
+            return us.value * 1e-6
+        if dist is not None:
+            import torch
+            t = torch.tensor([seconds], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t[0])
+        return seconds
+
+    def measure(pot, meth, steps, warmup, nx=None, mem=False):
         """One Simulation of `pot`/`meth`: W untimed steps, then exactly K steps between barrier + device syncs."""
+        nx = nx or a.nx
         pairlist = meth == "cta_cell_pairlist"                # the reference's -L: pairlist bits for the CTA-per-cell LJ kernel
-        args = ["-x", a.nx * px, "-y", a.nx * py, "-z", a.nx * pz, "-i", px, "-j", py, "-k", pz,
+        args = ["-x", nx * px, "-y", nx * py, "-z", nx * pz, "-i", px, "-j", py, "-k", pz,
                 "-m", "cta_cell" if pairlist else meth, "-a", use_async] + (["-e"] if pot == "eam" else []) + (["-L"] if pairlist else [])
+        free0 = pkg.device_mem_info()[0] if mem else 0
         sim = pkg.Simulation(args)
+        free1 = pkg.device_mem_info()[0] if mem else 0
 
         def sync_all():
             hip.comdDeviceSynchronize()
-            if dist is not None:
-                dist.barrier()
+            barrier()
             hip.comdDeviceSynchronize()
 
         sim.step(warmup)
         sync_all()
+        free2 = pkg.device_mem_info()[0] if mem else 0
         sim.force_timing(True)
         builds0 = sim.nl_builds
         t0 = time.perf_counter()
         sim.step(steps)
         sync_all()
-        elapsed = time.perf_counter() - t0
+        elapsed = max_over_ranks(time.perf_counter() - t0)
         force_ms, n_launch = sim.force_timing_total()
+        aux_ms, _ = sim.force_timing_aux()
         sim.force_timing(False)
-        if dist is not None:
-            import torch
-            t = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t[0])
         ep, ek, n_global = sim.energy()
         sim.sum_atoms()
         assert sim.energy()[2] == n_global, "atoms were lost"
-        res = {"elapsed": elapsed, "force_ms": force_ms, "launches": n_launch, "ep": ep, "ek": ek, "n_global": n_global,
-               "cap": sim.max_atoms, "nl_builds": sim.nl_builds - builds0}
+        res = {"elapsed": elapsed, "force_ms": force_ms, "aux_ms": aux_ms, "launches": n_launch, "ep": ep, "ek": ek, "n_global": n_global,
+               "cap": sim.max_atoms, "nl_builds": sim.nl_builds - builds0,
+               "mem_GB": {"simulation": (free0 - free1) / 1e9, "allocated_by_the_first_steps": (free1 - free2) / 1e9} if mem else None}
         sim.close()
         return res
 
-    import ctypes
-    hip = pkg.lib_hip()
     m = measure(a.pot, method, a.steps, a.warmup)
     elapsed, force_ms, n_global, ep, ek = m["elapsed"], m["force_ms"], m["n_global"], m["ep"], m["ek"]
 
     if rank == 0:
         n_local = n_global / a.gpus
         value = n_global * a.steps / elapsed
-        force_per_step_ms = force_ms / a.steps                 # all force launches of one step on rank 0
-        flop = (FORCE_FLOP_NL if method.endswith("_nl") else FORCE_FLOP)[a.pot]
-        if a.pot == "lj" and method == "thread_atom" and os.environ.get("COMD_LJ_PRUNE", "1") != "0":
-            flop = FORCE_FLOP_LISTED["lj"]
-        achieved = FORCE_BYTES[a.pot] * n_local / (force_per_step_ms * 1e-3) / 1e9 if force_ms > 0 else None
+        roof = roofline_object(a.pot, method, a.nx, n_local, force_ms / a.steps, m["aux_ms"] / a.steps, a.precision, one_gpu=a.gpus == 1)
+        roof.update({"launches_timed": m["launches"], "whole_step_achieved_GBs": STEP_BYTES[a.pot] * value / a.gpus / 1e9,
+                     "note": "fp64 ALU-bound stencil: ~4000 (LJ; ~2350 after the per-wave box pruning of thread_atom) / ~283 (EAM) candidate pairs per atom against 56 / 176 algorithmic bytes (SURVEY.md 8d)"})
         out = {
             "metric": "atom_updates_per_sec", "value": value, "unit": "atom-updates/s",
             "n_gpus": a.gpus, "steps": a.steps, "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps,
@@ -263,17 +317,7 @@ def main():
                        **({"transport": transport_name or ("rccl-loopback" if loopback else "rccl")} if a.gpus > 1 or loopback else {})},
             "per_gpu_value": value / a.gpus,
             "energy_per_atom_eV": (ep + ek) / n_global,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
-                         "traffic": measured_traffic(a.pot, method, a.nx) if a.gpus == 1 else None,
-                         "kernel": KERNEL_NAME[(a.pot, method)],
-                         "kernel_ms_per_step": force_per_step_ms, "launches_timed": m["launches"],
-                         "algorithmic_bytes_per_atom": FORCE_BYTES[a.pot],
-                         "whole_step_achieved_GBs": STEP_BYTES[a.pot] * value / a.gpus / 1e9,
-                         ("fp64_vector" if a.precision == "double" else "fp32_vector"): {"achieved_TFLOPs": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 if force_ms > 0 else None,
-                                         "peak_TFLOPs": FP64_VECTOR_PEAK_TFLOPS, "flop_per_atom": flop,
-                                         "frac": flop * n_local / (force_per_step_ms * 1e-3) / 1e12 / FP64_VECTOR_PEAK_TFLOPS if force_ms > 0 else None},
-                         "note": "fp64 ALU-bound stencil: ~4000 (LJ; ~2350 after the per-wave box pruning of thread_atom) / ~283 (EAM) candidate pairs per atom against 56 / 176 algorithmic bytes (SURVEY.md 8d)"},
+            "roofline": roof,
         }
         if method == "thread_atom_nl":
             out["config"]["neighbor_list_builds_timed"] = m["nl_builds"]
@@ -288,16 +332,21 @@ def main():
             if (pot, meth) == (a.pot, method):
                 continue
             v = measure(pot, meth, a.steps, a.warmup)
-            variants.append({"workload": f"{pot.upper()} Cu FCC {a.nx}^3, {meth}", "value": v["n_global"] * a.steps / v["elapsed"],
-                             "ms_per_step": 1e3 * v["elapsed"] / a.steps, "force_ms_per_step": v["force_ms"] / a.steps,
-                             "energy_per_atom_eV": (v["ep"] + v["ek"]) / v["n_global"], "cell_capacity": v["cap"],
-                             **({"neighbor_list_builds_timed": v["nl_builds"]} if meth.endswith(("_nl", "_pairlist")) else {})})
+            entry = {"workload": f"{pot.upper()} Cu FCC {a.nx}^3, {meth}", "value": v["n_global"] * a.steps / v["elapsed"],
+                     "ms_per_step": 1e3 * v["elapsed"] / a.steps, "force_ms_per_step": v["force_ms"] / a.steps,
+                     "force_evaluation_ms": (v["force_ms"] + v["aux_ms"]) / a.steps,
+                     "energy_per_atom_eV": (v["ep"] + v["ek"]) / v["n_global"], "cell_capacity": v["cap"],
+                     **({"neighbor_list_builds_timed": v["nl_builds"]} if meth.endswith(("_nl", "_pairlist")) else {})}
+            if (pot, meth) in (("eam", "cta_cell"), ("lj", "thread_atom")):      # BASELINE.json configs[2] / configs[1]: a roofline object of their own
+                entry["baseline_config"] = "configs[2]" if pot == "eam" else "configs[1]"
+                entry["roofline"] = roofline_object(pot, meth, a.nx, v["n_global"], v["force_ms"] / a.steps, v["aux_ms"] / a.steps, a.precision)
+            variants.append(entry)
     # the single-precision build on the two BASELINE workloads: a child process each (the two builds export the same symbols)
     if a.gpus == 1 and not a.no_variants and a.precision == "double":
         import subprocess
         for pot in ("lj", "eam"):
             cmd = [sys.executable, os.path.abspath(__file__), "--precision", "single", "--pot", pot, "--steps", str(a.steps), "--warmup", str(a.warmup),
-                   "--nx", str(a.nx), "--no-variants", "--no-cpu-baseline"]
+                   "--nx", str(a.nx), "--no-variants", "--no-cpu-baseline", "--no-target-line"]
             try:
                 child = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
                 v = json.loads(child.stdout.strip().splitlines()[-1])
@@ -306,15 +355,37 @@ def main():
                                  "cell_capacity": v["config"]["cell_capacity"]})
             except Exception as exc:                          # a variant line must never take the headline down with it
                 variants.append({"workload": f"{pot.upper()} Cu FCC {a.nx}^3, PRECISION=single build", "dtype": "f32", "error": repr(exc)[:200]})
+    # BASELINE.json's target line: LJ 256^3 on one GPU (north_star: ">= 50 % of the HBM roofline on LJ force at 256^3")
+    target = None
+    if a.gpus == 1 and not a.no_variants and not a.no_target_line and a.precision == "double" and not loopback:
+        free, total = pkg.device_mem_info()
+        if free < 60e9:
+            target = {"workload": "LJ Cu FCC 256^3, thread_atom", "skipped": f"{free / 1e9:.0f} GB of device memory free, the leg needs ~45 GB (atoms 16 GB, candidate lists 17 GB, packed positions 6 GB) and asks for 60"}
+        else:
+            try:
+                t = measure("lj", "thread_atom", 3, 1, nx=256, mem=True)
+                ms = 1e3 * t["elapsed"] / 3
+                roof = roofline_object("lj", "thread_atom", 256, t["n_global"], t["force_ms"] / 3, t["aux_ms"] / 3, "double")
+                target = {"workload": f"LJ Cu FCC 256^3 ({t['n_global']} atoms), thread_atom, fp64, 3 timed steps after 1", "value": t["n_global"] * 3 / t["elapsed"],
+                          "unit": "atom-updates/s", "ms_per_step": ms, "kernel_ms_per_step": t["force_ms"] / 3, "force_evaluation_ms": (t["force_ms"] + t["aux_ms"]) / 3,
+                          "hbm_frac": roof["frac"], "fp64_vector_frac": roof["fp64_vector"]["frac"], "energy_per_atom_eV": (t["ep"] + t["ek"]) / t["n_global"],
+                          "device_memory_GB": t["mem_GB"], "note": "north_star asks for >= 50 % of the HBM roof on this line; a 5-sigma fp64 stencil is VALU-bound near 7 % (SURVEY.md 0.10, DESIGN.md 3)"}
+            except Exception as exc:
+                target = {"workload": "LJ Cu FCC 256^3, thread_atom", "error": repr(exc)[:300]}
     if rank == 0:
         if variants:
             out["variants"] = variants
+        if target:
+            out["target_line"] = target
         if a.gpus == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a.pot, a.cpu_seconds)
         print(json.dumps(out))
-    if dist is not None:
+    if transport is not None:
+        barrier()
+        hip.comdCommFinalize()
+    elif dist is not None:
         dist.barrier()
-        pkg.lib_hip().comdCommFinalize()
+        hip.comdCommFinalize()
         dist.destroy_process_group()
 
 

@@ -83,6 +83,11 @@ def lib_hip():
         lib.comdForceTimingReset.argtypes = [ctypes.c_void_p]
         lib.comdForceTimingTotalMs.argtypes = [ctypes.c_void_p, c_int_p]
         lib.comdForceTimingTotalMs.restype = ctypes.c_double
+        lib.comdForceTimingAuxMs.argtypes = [ctypes.c_void_p, c_int_p]
+        lib.comdForceTimingAuxMs.restype = ctypes.c_double
+        lib.comdDeviceMemInfo.argtypes = [ctypes.POINTER(ctypes.c_long), ctypes.POINTER(ctypes.c_long)]
+        lib.comdCommInitFromEnv.argtypes = [ctypes.POINTER(CommTransport), c_int_p, c_int_p, c_int_p]
+        lib.comdCommInitFromEnv.restype = ctypes.c_int
         lib.comdCommInfo.argtypes = [c_int_p, c_int_p, c_int_p]
         lib.comdCommInfo.restype = ctypes.c_int
         lib.comdEventCreate.restype = ctypes.c_void_p
@@ -168,6 +173,22 @@ def rccl_transport(rank, n_ranks, unique_id):
     if rc != 0:
         raise RuntimeError("comdCommInitRank failed")
     return t
+
+
+def rccl_transport_from_env():
+    """Join the RCCL communicator the way comd-hip does (comdCommInitFromEnv: RANK / WORLD_SIZE / LOCAL_RANK, rendezvous through a file keyed by
+    the launcher's pid).  No torch, no second HIP runtime in the process.  Returns the transport, or None when the communicator cannot be formed."""
+    t = CommTransport()
+    r, n, l = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+    if lib_hip().comdCommInitFromEnv(ctypes.byref(t), ctypes.byref(r), ctypes.byref(n), ctypes.byref(l)) != 0:
+        return None
+    return t
+
+
+def device_mem_info():
+    f, t = ctypes.c_long(0), ctypes.c_long(0)
+    lib_hip().comdDeviceMemInfo(ctypes.byref(f), ctypes.byref(t))
+    return f.value, t.value
 
 
 def rccl_comm_info():
@@ -263,6 +284,12 @@ class Simulation:
         """(milliseconds, launches) of the force kernels since force_timing(True)."""
         n = ctypes.c_int(0)
         ms = lib_hip().comdForceTimingTotalMs(ctypes.c_void_p(self.lib.comdSimGpu(self.ptr)), ctypes.byref(n))
+        return ms, int(n.value)
+
+    def force_timing_aux(self):
+        """(milliseconds, launches) of what the force evaluations launched beside the force kernels (list builds, cell marks)."""
+        n = ctypes.c_int(0)
+        ms = lib_hip().comdForceTimingAuxMs(ctypes.c_void_p(self.lib.comdSimGpu(self.ptr)), ctypes.byref(n))
         return ms, int(n.value)
 
     # --- results ---

@@ -36,11 +36,15 @@ static inline hipStream_t S(comdStream_t s) { return (hipStream_t)s; }
 static inline int ceilDiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- force-kernel timing (bench.py roofline leg): per simulation, SimGpu.timing -----------------------------------
+// Two classes of launches are timed apart: kind 0 the force kernels proper (the kernel the roofline object names), kind 1 what a force
+// evaluation launches beside them (LJ thread_atom: LJ_PackPositions + LJ_WaveCandidates; the cell marks of a list launch).  A force
+// EVALUATION costs the sum of the two.
 struct ForceTiming {
-   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+   struct Ev { hipEvent_t a, b; int kind; };
+   std::vector<Ev> pool;
    size_t used = 0;
-   double ms = 0.0;
-   int launches = 0;
+   double ms[2] = { 0.0, 0.0 };
+   int launches[2] = { 0, 0 };
    bool on = false;
 };
 
@@ -49,27 +53,28 @@ static void timingFlush(ForceTiming* t)
    if (!t) return;
    for (size_t i = 0; i < t->used; ++i) {
       float ms = 0.f;
-      HIP_CHECK(hipEventSynchronize(t->pool[i].second));
-      HIP_CHECK(hipEventElapsedTime(&ms, t->pool[i].first, t->pool[i].second));
-      t->ms += ms;
+      HIP_CHECK(hipEventSynchronize(t->pool[i].b));
+      HIP_CHECK(hipEventElapsedTime(&ms, t->pool[i].a, t->pool[i].b));
+      t->ms[t->pool[i].kind] += ms;
+      t->launches[t->pool[i].kind] += 1;
    }
-   t->launches += (int)t->used;
    t->used = 0;
 }
 
 struct ForceTimer {
    ForceTiming* t; hipStream_t st; int idx;
-   ForceTimer(SimGpu* sim, hipStream_t s) : t((ForceTiming*)sim->timing), st(s), idx(-1)
+   ForceTimer(SimGpu* sim, hipStream_t s, int kind = 0) : t((ForceTiming*)sim->timing), st(s), idx(-1)
    {
       if (!t || !t->on) return;
       if (t->used == t->pool.size()) {
          if (t->pool.size() >= 1024) timingFlush(t);
-         else { hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); t->pool.push_back({a, b}); }
+         else { hipEvent_t a, b; HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b)); t->pool.push_back({a, b, 0}); }
       }
       idx = (int)t->used++;
-      HIP_CHECK(hipEventRecord(t->pool[idx].first, st));
+      t->pool[idx].kind = kind;
+      HIP_CHECK(hipEventRecord(t->pool[idx].a, st));
    }
-   ~ForceTimer() { if (idx >= 0) HIP_CHECK(hipEventRecord(t->pool[idx].second, st)); }
+   ~ForceTimer() { if (idx >= 0) HIP_CHECK(hipEventRecord(t->pool[idx].b, st)); }
 };
 
 extern "C" void comdForceTimingEnable(SimGpu* sim, int on)
@@ -81,15 +86,31 @@ extern "C" void comdForceTimingReset(SimGpu* sim)
 {
    ForceTiming* t = (ForceTiming*)sim->timing;
    if (!t) return;
-   timingFlush(t); t->ms = 0.0; t->launches = 0;
+   timingFlush(t); t->ms[0] = t->ms[1] = 0.0; t->launches[0] = t->launches[1] = 0;
 }
 extern "C" double comdForceTimingTotalMs(SimGpu* sim, int* nLaunches)
 {
    ForceTiming* t = (ForceTiming*)sim->timing;
    if (!t) { if (nLaunches) *nLaunches = 0; return 0.0; }
    timingFlush(t);
-   if (nLaunches) *nLaunches = t->launches;
-   return t->ms;
+   if (nLaunches) *nLaunches = t->launches[0];
+   return t->ms[0];
+}
+extern "C" double comdForceTimingAuxMs(SimGpu* sim, int* nLaunches)
+{
+   ForceTiming* t = (ForceTiming*)sim->timing;
+   if (!t) { if (nLaunches) *nLaunches = 0; return 0.0; }
+   timingFlush(t);
+   if (nLaunches) *nLaunches = t->launches[1];
+   return t->ms[1];
+}
+
+extern "C" void comdDeviceMemInfo(long* freeBytes, long* totalBytes)
+{
+   size_t f = 0, tot = 0;
+   HIP_CHECK(hipMemGetInfo(&f, &tot));
+   if (freeBytes) *freeBytes = (long)f;
+   if (totalBytes) *totalBytes = (long)tot;
 }
 
 extern "C" void* comdEventCreate(void) { hipEvent_t e; HIP_CHECK(hipEventCreate(&e)); return (void*)e; }
@@ -357,7 +378,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
    if (sim->timing) {
       ForceTiming* t = (ForceTiming*)sim->timing;
       timingFlush(t);
-      for (auto& ev : t->pool) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+      for (auto& ev : t->pool) { (void)hipEventDestroy(ev.a); (void)hipEventDestroy(ev.b); }
       delete t;
    }
    void* ptrs[] = { sim->boxes.nAtoms, sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
@@ -489,6 +510,7 @@ static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int*
       wl.grow = sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5);
       // interior cells never have a halo cell in their stencil, and the halo cells are being filled while they run
       const int packCells = (cells_list && stream == sim->interior_stream) ? sim->boxes.nLocalBoxes : sim->boxes.nTotalBoxes;
+      ForceTimer aux(sim, S(stream), 1);               // the list build of this evaluation (bench.py: force_evaluation_ms = kernel + this)
       hipLaunchKernelGGL(LJ_PackPositions, dim3((unsigned)ceilDiv((long)packCells * lj->packedCap, 256)), dim3(256), 0, S(stream),
                          a.rx, a.ry, a.rz, a.nAtoms, (LjPos4*)lj->packedR[which], a.cap, lj->packedCap, packCells, a.rc2);
       hipLaunchKernelGGL(LJ_WaveCandidates, dim3((unsigned)ceilDiv(num_cells, 4)), dim3(256), 0, S(stream), a, wl, w);
@@ -661,6 +683,7 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
          HIP_CHECK(hipMemsetAsync(sim->eam_pot.cellSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(int), st));
       }
       b.sel = sim->eam_pot.cellSel; b.tag = ++sim->eam_pot.selTag;
+      ForceTimer aux(sim, st, 1);
       hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(num_cells, 256)), dim3(256), 0, st, cells_list, num_cells, sim->eam_pot.cellSel, b.tag);
    }
    int waves = 4;

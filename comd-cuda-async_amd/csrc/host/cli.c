@@ -2,7 +2,8 @@
  * flags, same defaults, same "Command Line Parameters" YAML block.  Table-driven over getopt_long.
  * Extensions (long options only): --maxAtoms N (link-cell slot capacity; the reference fixes it at
  * compile time with -DMAXATOMS), --maxNeighbors N (Verlet-list rows per atom for the *_nl methods; the reference's
- * MAXNEIGHBORLISTSIZE), --quiet, --ljCutoffSigmas F (the reference hard-wires 5; 2.5 meets its documented LJ cohesive energy). */
+ * MAXNEIGHBORLISTSIZE), --quiet, --ljCutoffSigmas F (the reference hard-wires 5; 2.5 meets its documented LJ cohesive energy),
+ * --deviceTimers (also COMD_DEVICE_TIMERS=1: HIP-event timing of the phases in the reference's timer table). */
 #include "comd_host.h"
 #include <getopt.h>
 #include <stdlib.h>
@@ -65,6 +66,7 @@ Command parseCommandLine(int argc, char** argv)
       { "maxNeighbors",  0,  1, 'i', &cmd.maxNeighbors,   0, "neighbour-list rows per atom for *_nl (0 = from cutoff + skin)" },
       { "quiet",         0,  0, 'i', &cmd.quiet,          0, "no stdout report" },
       { "ljCutoffSigmas", 0, 1, 'd', &cmd.ljCutoffSigmas, 0, "LJ cutoff in sigmas (5 as in ljForce.c:114; 2.5 reproduces the cohesive energy of CoMD.c:897)" },
+      { "deviceTimers",  0,  0, 'i', &cmd.deviceTimers,   0, "time the phases of timestep() with HIP events on the device (the host timers of the reference see launches, not kernels)" },
    };
    const int nDefs = (int)(sizeof defs / sizeof defs[0]);
 

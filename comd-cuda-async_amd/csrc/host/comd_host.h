@@ -41,6 +41,7 @@ typedef struct CommandSt {
    int doHilbert, gpuAsync, gpuProfile, ljInterpolation, spline, usePairlist, maxNeighbors;
    int maxAtoms;          /* extension: link-cell slot capacity, 0 = choose from the lattice (reference: -DMAXATOMS) */
    int quiet;             /* extension: suppress the stdout report (library use) */
+   int deviceTimers;      /* extension: HIP-event timing of the phases of timestep() (the reference's host timers are not device-synchronised) */
    double ljCutoffSigmas; /* extension (tests): LJ cutoff in sigmas; 5 = the reference (ljForce.c:114), 2.5 = upstream CoMD, whose cohesive energy CoMD.c:897 documents */
 } Command;
 
@@ -291,6 +292,9 @@ void profileStart(enum TimerHandle handle);
 void profileStop(enum TimerHandle handle);
 double getElapsedTime(enum TimerHandle handle);
 void resetTimers(void);
+/* device-true timing: every start/stop of a phase of timestep() also records a HIP event on `stream`; the report then shows device seconds for those
+ * phases (same table, same YAML keys) and adds atomUpdatesPerSec / forceKernelGBs.  forceBytesPerAtom: algorithmic bytes of one force evaluation. */
+void timersUseDevice(int on, comdStream_t stream, double forceBytesPerAtom);
 void printPerformanceResults(int nGlobalAtoms, int printRate);
 void printPerformanceResultsYaml(FILE* file);
 #define startTimer(h) profileStart(h)

@@ -347,6 +347,8 @@ int comdMain(int argc, char** argv)
    printCmdYaml(screenOut, &cmd);
 
    SimFlat* sim = initSimulation(cmd);
+   if (cmd.deviceTimers || (getenv("COMD_DEVICE_TIMERS") && atoi(getenv("COMD_DEVICE_TIMERS")) != 0))
+      timersUseDevice(1, sim->gpu.boundary_stream, cmd.doeam ? 176.0 * sizeof(real_t) / 8.0 : 56.0 * sizeof(real_t) / 8.0);      /* force bytes per atom */
    sumAtoms(sim);
    printSimulationDataYaml(yamlFile, sim);
    printSimulationDataYaml(screenOut, sim);
@@ -388,6 +390,8 @@ SimFlat* comdCreate(int argc, char** argv)
 {
    Command cmd = parseCommandLine(argc, argv);
    SimFlat* sim = initSimulation(cmd);
+   if (cmd.deviceTimers || (getenv("COMD_DEVICE_TIMERS") && atoi(getenv("COMD_DEVICE_TIMERS")) != 0))
+      timersUseDevice(1, sim->gpu.boundary_stream, cmd.doeam ? 176.0 * sizeof(real_t) / 8.0 : 56.0 * sizeof(real_t) / 8.0);      /* force bytes per atom */
    sumAtoms(sim);
    return sim;
 }

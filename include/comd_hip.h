@@ -453,6 +453,11 @@ void   comdEventDestroy(void* ev);
 void   comdForceTimingEnable(SimGpu* sim, int on);
 void   comdForceTimingReset(SimGpu* sim);
 double comdForceTimingTotalMs(SimGpu* sim, int* nLaunches);
+/* ... and of what a force evaluation launches beside them (LJ thread_atom: LJ_PackPositions + LJ_WaveCandidates; the cell marks of an EAM launch
+ * over a cell list): one force EVALUATION costs comdForceTimingTotalMs + comdForceTimingAuxMs */
+double comdForceTimingAuxMs(SimGpu* sim, int* nLaunches);
+/* hipMemGetInfo: free and total device memory in bytes (bench.py sizes its 256^3 leg against it) */
+void   comdDeviceMemInfo(long* freeBytes, long* totalBytes);
 
 #ifdef __cplusplus
 }
