@@ -461,6 +461,25 @@ static LjArgs makeLjArgs(SimGpu* sim, int num_cells, int* cells_list)
 // force evaluations feed no energy read (all but the last step of a timestep() call); the default is 1 (always compute).
 extern "C" void comdSetEnergyNeeded(SimGpu* sim, int on) { sim->needEnergy = on; }
 
+// Margins of the point-to-box pruning test (LJ_WaveCandidates, LJ_Force_cta_cell_boxes): the test may keep a candidate it need not, never drop one a
+// lane would accept.  A relative margin on rc^2 and on the half widths covers the arithmetic of the distance; the box CENTRE is formed from absolute
+// coordinates, whose ulp grows with the box (float: 3e-5 A at 289 A, 1.2e-4 A beyond 1024 A -- ADVICE r2), so the cutoff is also pushed out by eight
+// ulps of the largest coordinate this rank can see (local domain + one halo cell), per axis.
+static void ljBoxMargins(const SimGpu* sim, real_t rc2, real_t* rc2Box, real_t* grow)
+{
+   const double rel = sizeof(real_t) == 8 ? 1e-12 : 1e-5, eps = sizeof(real_t) == 8 ? 2.220446049250313e-16 : 1.1920929e-07;
+   double big = 0.0;
+   for (int a = 0; a < 3; ++a) {
+      const double cellW = 1.0 / sim->boxes.invBoxSize[a];
+      const double lo = fabs((double)sim->boxes.localMin[a] - cellW), hi = fabs((double)sim->boxes.localMax[a] + cellW);
+      if (lo > big) big = lo;
+      if (hi > big) big = hi;
+   }
+   const double rc = sqrt((double)rc2) * (1.0 + rel) + 8.0 * 1.7320508 * eps * big;
+   *rc2Box = (real_t)(rc * rc);
+   *grow = (real_t)(1.0 + rel);
+}
+
 // thread_atom (the BASELINE-named kernel): candidate lists, then the force kernel
 static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int* cells_list, comdStream_t stream)
 {
@@ -491,8 +510,18 @@ static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int*
       { const char* e = getenv("COMD_LJ_LIST_CAP"); if (e && atoi(e) > 0) lj->waveCandCap = (atoi(e) + 7) & ~7; }
       lj->packedCap = ((occ + 7) & ~7) < sim->maxAtoms ? ((occ + 7) & ~7) : sim->maxAtoms;     // a stencil with a fuller cell falls back to the walk
       // list entries are 32-bit byte offsets into the packed records
+      // ~250 B of list per atom (18 GB at 256^3) + the packed records (2.9 GB each): when that does not fit what the device has free (keeping 2 GB
+      // for everything allocated later), or the 32-bit offsets cannot reach the records, this simulation walks the stencil as round 1 did
+      const double listBytes = (double)sim->boxes.nLocalBoxes * lj->waveCandWaves * lj->waveCandCap * 4.0 + (double)sim->boxes.nLocalBoxes * lj->waveCandWaves * 8.0
+                               + (sim->interior_stream ? 2.0 : 1.0) * (double)sim->boxes.nTotalBoxes * lj->packedCap * sizeof(LjPos4);
+      size_t freeB = 0, totalB = 0;
+      HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
       if ((double)sim->boxes.nTotalBoxes * lj->packedCap * sizeof(LjPos4) >= 4294967296.0) lj->packedCap = -1;     // no lists for this simulation
-      else {
+      else if (listBytes + 2.0e9 > (double)freeB || (getenv("COMD_LJ_LIST_BUDGET_MB") && listBytes > 1.0e6 * atof(getenv("COMD_LJ_LIST_BUDGET_MB")))) {
+         fprintf(stderr, "Rank %d: LJ candidate lists need %.1f GB, %.1f GB are free: running without them (the plain 27-cell walk, ~1.4x slower)\n",
+                 g_rank, listBytes / 1e9, (double)freeB / 1e9);
+         lj->packedCap = -1;
+      } else {
          lj->waveCand = dalloc<unsigned>((size_t)sim->boxes.nLocalBoxes * lj->waveCandWaves * lj->waveCandCap, false);
          lj->waveCandCount = dalloc<int>((size_t)sim->boxes.nLocalBoxes * lj->waveCandWaves * 2, false);
       }
@@ -506,8 +535,7 @@ static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int*
       if (!lj->packedR[which]) lj->packedR[which] = dalloc<real_t>((size_t)sim->boxes.nTotalBoxes * lj->packedCap * 4, false);
       wl.cand = lj->waveCand; wl.pos = (const LjPos4*)lj->packedR[which]; wl.count = (int2*)lj->waveCandCount;
       wl.candCap = lj->waveCandCap; wl.wavesMax = lj->waveCandWaves; wl.capP = lj->packedCap;
-      wl.rc2Box = a.rc2 * (sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5));
-      wl.grow = sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5);
+      ljBoxMargins(sim, a.rc2, &wl.rc2Box, &wl.grow);
       // interior cells never have a halo cell in their stencil, and the halo cells are being filled while they run
       const int packCells = (cells_list && stream == sim->interior_stream) ? sim->boxes.nLocalBoxes : sim->boxes.nTotalBoxes;
       ForceTimer aux(sim, S(stream), 1);               // the list build of this evaluation (bench.py: force_evaluation_ms = kernel + this)
@@ -576,8 +604,8 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
                             else              hipLaunchKernelGGL((LJ_Force_cta_cell<PLV, false>), dim3(num_cells), dim3(threads), lds, S(stream), a, sim->status, pl); } while (0)
       if (n->slabFormat != 3 && !(getenv("COMD_LJ_CTA_SLABS") && atoi(getenv("COMD_LJ_CTA_SLABS")) != 0)) {
          // the default form: every wave stages its own box-pruned candidates (COMD_LJ_CTA_SLABS=1: the slab kernel, for A/B runs)
-         const real_t rc2Box = a.rc2 * (sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5));
-         const real_t grow = sizeof(real_t) == 8 ? (real_t)(1.0 + 1e-12) : (real_t)(1.0 + 1e-5);
+         real_t rc2Box, grow;
+         ljBoxMargins(sim, a.rc2, &rc2Box, &grow);
          const size_t ldsB = ljCtaBoxesLdsBytes(threads);
          if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_cta_cell_boxes<true>, dim3(num_cells), dim3(threads), ldsB, S(stream), a, rc2Box, grow);
          else                 hipLaunchKernelGGL(LJ_Force_cta_cell_boxes<false>, dim3(num_cells), dim3(threads), ldsB, S(stream), a, rc2Box, grow);

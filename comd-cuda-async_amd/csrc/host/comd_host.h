@@ -175,6 +175,7 @@ typedef struct HaloSpecSt {
    int*  mirror;                          /* pinned [4] */
    void* event;
    int   haveBound, lastBound[4];         /* sizes the previous exchange was posted with: a count above its bound means that exchange was cut short */
+   int   lastCount[4];                    /* ... and the counts those sizes were derived from (both ends of a message hold the same two numbers) */
 } HaloSpec;
 
 typedef struct HaloExchangeSt {

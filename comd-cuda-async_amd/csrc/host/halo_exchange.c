@@ -494,6 +494,19 @@ static int boundOf(int last, int capacityAtoms)
    return b > capacityAtoms ? capacityAtoms : (int)b;
 }
 
+/* A message that used more than half of its slack in ONE step is growing fast (a shock front, a melting surface): its next transfer gets four times the
+ * slack -- + 50 % + 256 atoms -- before the run would have to stop a step later.  Decided per MESSAGE from two numbers both of its ends hold
+ * (this count and the count its last bound was derived from), so sender and receiver still agree without talking; ranks with three or more neighbours
+ * on an axis need exactly that -- a per-rank switch to the handshake would not be symmetric. */
+static int boundGrowing(int now, int before, int lastBound, int capacityAtoms)
+{
+   const int normal = boundOf(now, capacityAtoms);
+   if (2L * (now - before) <= (long)lastBound - before) return normal;
+   long wide = (long)now + now / 2 + 256;
+   if (wide < normal) wide = normal;
+   return wide > capacityAtoms ? capacityAtoms : (int)wide;
+}
+
 void exchangeData(HaloExchange* hh, void* data, int iAxis)
 {
    const int faceM = 2 * iAxis, faceP = faceM + 1;
@@ -513,8 +526,10 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
                             "exchange %d, axis %d).  COMD_HALO_HANDSHAKE=1 exchanges exact sizes.\n", getMyRank(), sp->mirror[i], sp->lastBound[i], hh->type, iAxis);
             exit(-1);
          }
-      for (int i = 0; i < 4; ++i) bound[i] = hh->exactCounts ? sp->mirror[i] : boundOf(sp->mirror[i], hh->capacityAtoms);
-      for (int i = 0; i < 4; ++i) sp->lastBound[i] = bound[i];
+      for (int i = 0; i < 4; ++i)
+         bound[i] = hh->exactCounts ? sp->mirror[i] : sp->haveBound ? boundGrowing(sp->mirror[i], sp->lastCount[i], sp->lastBound[i], hh->capacityAtoms)
+                                                                    : boundOf(sp->mirror[i], hh->capacityAtoms);
+      for (int i = 0; i < 4; ++i) { sp->lastBound[i] = bound[i]; sp->lastCount[i] = sp->mirror[i]; }
       sp->haveBound = 1;
       if (hh->setBounds) { hh->setBounds(hh->parms, faceM, bound[0], bound[3]); hh->setBounds(hh->parms, faceP, bound[1], bound[2]); }
    }

@@ -126,7 +126,7 @@ def test_eam_cells_whose_stencil_outgrows_the_lds_slice(gpu, orc, monkeypatch, s
         assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < TOL["eam_dfembed_abs"]
 
 
-@pytest.mark.parametrize("env", [{"COMD_LJ_PRUNE": "0"}, {"COMD_LJ_LIST_CAP": "64"}, {"COMD_LJ_LIST_CAP": "2200"}, {}])
+@pytest.mark.parametrize("env", [{"COMD_LJ_PRUNE": "0"}, {"COMD_LJ_LIST_CAP": "64"}, {"COMD_LJ_LIST_CAP": "2200"}, {"COMD_LJ_LIST_BUDGET_MB": "1"}, {}])
 def test_lj_wave_candidate_lists_and_their_fallbacks(gpu, orc, monkeypatch, env):
     """thread_atom tests only the stencil atoms within the cutoff of each wave's bounding box (LJ_WaveCandidates).  The four legs: lists
     off (the plain 27-cell walk), rows too short for any wave (every wave falls back to the walk), rows that fit the tail waves' lists but
