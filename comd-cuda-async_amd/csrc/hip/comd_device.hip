@@ -679,15 +679,45 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    b.by = 4; b.bz = 2;
    { const char* e = getenv("COMD_EAM_BRICK"); int y = 0, z = 0; if (e && sscanf(e, "%d,%d", &y, &z) == 2 && y >= 1 && z >= 1 && 3 * (y + 2) * (z + 2) <= EAM_BRICK_MAX_CELLS && y * z <= 64) { b.by = y; b.bz = z; } }
    b.nby = ceilDiv(b.geom.g[1], b.by); b.nbz = ceilDiv(b.geom.g[2], b.bz);
-   // the image: the block's cells at the perfect-lattice density + 15 % (the sum over 72 cells fluctuates far less than one cell) + 48
+   // The image must hold the atoms of the fullest BLOCK (3 x (by + 2) x (bz + 2) cells), not the mean: the lattice and the cell grid are incommensurate,
+   // and at 80^3 the blocks of a 1 x 4 x 2 brick hold 755 atoms on average and up to 918.  A brick whose block outgrows the image takes the
+   // thread-per-atom form (correct, many times slower), so the first launch reads the occupancies once, finds the fullest block of this brick shape and
+   // sizes the image for it + 1 % + 8 (blocks gain or lose a handful of atoms through their surface as the lattice moves).  Both passes use that size.
    const double cellVol = 1.0 / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);
    const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
-   const int blockCells = 3 * (b.by + 2) * (b.bz + 2);
-   const double perBlock = blockCells * cellVol * 4.0 / (lat * lat * lat);
-   b.imageCap = (((int)(perBlock * 1.15) + 48 + 7) / 8) * 8;
-   if (b.imageCap < 256) b.imageCap = 256;
-   if (b.imageCap > 4096) b.imageCap = 4096;                 // 16-bit numbers would reach 65535; beyond 4096 records the cells take the thread-per-atom form
-   { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) b.imageCap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force the fallback
+   if (!sim->eam_pot.brickImageCap) {
+      std::vector<int> counts((size_t)sim->boxes.nTotalBoxes), lookup;
+      HIP_CHECK(hipMemcpyAsync(counts.data(), sim->boxes.nAtoms, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+      if (sim->boxes.boxIDLookUp) {
+         lookup.resize((size_t)sim->boxes.nLocalBoxes);
+         HIP_CHECK(hipMemcpyAsync(lookup.data(), sim->boxes.boxIDLookUp, lookup.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+      }
+      HIP_CHECK(hipStreamSynchronize(st));
+      CellGeom hg = b.geom; hg.lookup = lookup.empty() ? nullptr : lookup.data(); hg.reverse = nullptr;
+      const int gx = hg.g[0], gy = hg.g[1], gz = hg.g[2];
+      // per (y, z) row of three x cells, then the (by + 2) x (bz + 2) window of rows around every brick
+      long fullest = 0;
+      std::vector<int> row3((size_t)gx * (gy + 2) * (gz + 2));
+      for (int z = -1; z <= gz; ++z) for (int y = -1; y <= gy; ++y) for (int x = 0; x < gx; ++x)
+         row3[(size_t)x + (size_t)gx * ((y + 1) + (size_t)(gy + 2) * (z + 1))] =
+            counts[comdBoxFromTuple(&hg, x - 1, y, z)] + counts[comdBoxFromTuple(&hg, x, y, z)] + counts[comdBoxFromTuple(&hg, x + 1, y, z)];
+      // (only blocks made of local cells count: with -a 1 the first launch runs while the halo cells are still being filled; the lattice is periodic, the
+      // blocks at the faces are no fuller than those inside.  A grid too small to have such blocks takes the mean density + 25 %.)
+      for (int bzI = 0; bzI < b.nbz; ++bzI) for (int byI = 0; byI < b.nby; ++byI) for (int x = 1; x < gx - 1; ++x) {
+         if (byI * b.by - 1 < 0 || byI * b.by + b.by > gy - 1 || bzI * b.bz - 1 < 0 || bzI * b.bz + b.bz > gz - 1) continue;
+         long sum = 0;
+         for (int z = bzI * b.bz - 1; z <= bzI * b.bz + b.bz; ++z)
+            for (int y = byI * b.by - 1; y <= byI * b.by + b.by; ++y) sum += row3[(size_t)x + (size_t)gx * ((y + 1) + (size_t)(gy + 2) * (z + 1))];
+         if (sum > fullest) fullest = sum;
+      }
+      if (fullest == 0) fullest = (long)(1.25 * 3 * (b.by + 2) * (b.bz + 2) * cellVol * 4.0 / (lat * lat * lat));
+      int cap = (((int)(fullest * 1.01) + 8 + 7) / 8) * 8;
+      if (cap < 256) cap = 256;
+      if (cap > 4096) cap = 4096;                            // 16-bit numbers would reach 65535; beyond 4096 records the cells take the thread-per-atom form
+      { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) cap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force the fallback
+      sim->eam_pot.brickImageCap = cap;
+   }
+   b.imageCap = sim->eam_pot.brickImageCap;
    // rows per atom: the cutoff sphere at that density + 50 %, a multiple of 8
    const double rc = sim->eam_pot.cutoff;
    int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
@@ -716,22 +746,6 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    }
    int waves = 4;
    { const char* e = getenv("COMD_EAM_BRICK_WAVES"); if (e && atoi(e) >= 4 && atoi(e) <= 16) waves = atoi(e); }
-   // The LDS decides how many workgroups share a CU (1280-byte granules, 160 KB per CU): walk the image down, never below the density + 8 % + 24,
-   // to where pass 1 or pass 3 gains a workgroup.  Both passes must use the same image (a brick either fits it or takes the other form, in both).
-   if (!getenv("COMD_EAM_IMAGE")) {
-      const size_t t1 = tablesInLds ? (size_t)2 * (a.rho.n + 3) + (sameGrid ? 0 : (a.phi.n + 3 - (a.rho.n + 3))) : 0, t3 = tablesInLds ? (size_t)(a.rho.n + 3) : 0;
-      auto perCu = [&](int step, int cap) {
-         const size_t bts = eamBrickLdsBytes(step, step == 1 ? t1 : t3, cap, b.rows, waves);
-         return bts > 160 * 1024 ? 0 : (int)(160 * 1024 / (((bts + 1279) / 1280) * 1280));
-      };
-      const int lo = (((int)(perBlock * 1.08) + 24 + 7) / 8) * 8;
-      int best = b.imageCap, bestScore = perCu(1, best) + perCu(3, best);
-      for (int cap = b.imageCap - 8; cap >= lo && cap >= 256; cap -= 8) {
-         const int score = perCu(1, cap) + perCu(3, cap);
-         if (score > bestScore) { bestScore = score; best = cap; }
-      }
-      b.imageCap = best;
-   }
    const size_t lds = eamBrickLdsBytes(STEP, tableDoubles, b.imageCap, b.rows, waves);
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
    const int grid = b.geom.g[0] * b.nby * b.nbz;

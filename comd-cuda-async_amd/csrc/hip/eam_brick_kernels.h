@@ -37,7 +37,7 @@ struct EamBrickArgs {
    int debug;                             // experiments (COMD_EAM_ABLATE): 1 no build sweeps, 2 no pair evaluation
 };
 
-__host__ __device__ static inline int eamBrickRowStrideL(int rows) { return rows + 8; }      // LDS row stride (entries): 16 bytes of padding spread the atoms' rows over the banks
+__host__ __device__ static inline int eamBrickRowStrideL(int rows) { return rows + 2; }      // LDS row stride (entries): one dword of padding walks the atoms' rows over the banks
 // per wave, pass 1 only: [16][stride] rows + [16] counts
 __host__ __device__ static inline size_t eamBrickWaveBytes(int step, int rows)
 {

@@ -84,6 +84,7 @@ typedef struct EamPotentialGpu {
    int     pairRowLen;                 /* neighbours a row can hold (<= 256) */
    /* cta_cell, brick form (round 3, hip/eam_brick_kernels.h): the selection marks of launches that cover a cell list (the cells with
     * cellSel[c] == the launch's tag); allocated on first use.  The rows above keep their layout, the numbers now index the LDS image of the atom's brick. */
+   int     brickImageCap;              /* host: records the LDS image of a brick holds, fixed by the first brick launch from the occupancies it finds */
    int*    cellSel;                    /* device [nLocalBoxes] */
    int     selTag;                     /* host: tag of the last list launch */
 } EamPotentialGpu;

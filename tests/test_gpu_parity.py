@@ -109,12 +109,16 @@ def test_lj_cta_cell_both_forms(gpu, orc, monkeypatch, env):
         assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
 
 
-@pytest.mark.parametrize("stencil", [128, 368])
-def test_eam_cells_whose_stencil_outgrows_the_lds_slice(gpu, orc, monkeypatch, stencil):
-    """cta_cell sizes a wave's LDS slice from the density (and trims it to where a third workgroup fits the CU); a cell whose 27-cell stencil
-    holds more atoms than the slice is walked thread-per-atom by the same wave, in pass 1 AND pass 3 (no rows are handed over for it).
-    COMD_EAM_STENCIL forces a slice that every cell (128) or part of the cells (368; the stencils of this box hold about 365 atoms) outgrow."""
-    monkeypatch.setenv("COMD_EAM_STENCIL", str(stencil))
+@pytest.mark.parametrize("env", [{"COMD_EAM_IMAGE": "128"}, {"COMD_EAM_IMAGE": "1000"}, {"COMD_EAM_BRICK": "2,2"}, {"COMD_EAM_BRICK": "3,5"},
+                                 {"COMD_EAM_CTA": "cell", "COMD_EAM_STENCIL": "128"}, {"COMD_EAM_CTA": "cell", "COMD_EAM_STENCIL": "368"}, {"COMD_EAM_CTA": "cell"}])
+def test_eam_cells_whose_stencil_outgrows_the_lds_slice(gpu, orc, monkeypatch, env):
+    """cta_cell stages the cells around a brick in an LDS image sized from the fullest block the first launch finds; a brick whose block holds more
+    atoms than the image is walked thread-per-atom by the same workgroup, in pass 1 AND pass 3 (no rows are handed over for it).  COMD_EAM_IMAGE
+    forces an image that every brick (128) or part of the bricks (1000; the blocks of this box hold 860-1170 atoms) outgrow; COMD_EAM_BRICK
+    other brick shapes, one that does not divide the grid; COMD_EAM_CTA=cell round 2's kernel (a wave stages every cell's stencil for itself), with
+    its own slice-overflow legs."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     with gpu.Simulation(_args(12, 1, 0.1, "cta_cell")) as sim:
         o = orc.Oracle(12, eam=1, delta=0.1, cap=max(sim.max_atoms, 64))
         sim.step(3)
