@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""Turn what profiles/r03_collect.sh left under gpurun_out/r03final/ into the tracked files of profiles/ (run from the repo root).
+
+    gpurun --timeout 1190 -- 'bash profiles/r03_collect.sh'     # on the MI355X box
+    python3 profiles/r03_summarize.py                            # here: copies, r03_traffic.json, r03_summary.md
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+F = os.path.join(ROOT, "gpurun_out", "r03final")
+P = os.path.join(ROOT, "profiles")
+N = 2048000
+PATHS = [("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("lj", "cta_cell"), ("eam", "cta_cell"), ("eam", "thread_atom_nl"), ("eam", "thread_atom")]
+KERN = {("lj", "thread_atom"): ["LJ_Force_thread_atom<false, true>"], ("lj", "thread_atom_nl"): ["LJ_Force_nl_slabs<false>"], ("lj", "cta_cell"): ["LJ_Force_cta_cell_boxes<false>"],
+        ("eam", "cta_cell"): ["EAM_Force_cta_brick<1", "EAM_Force_cta_brick<3"], ("eam", "thread_atom_nl"): ["EAM_Force_nl_lds<1", "EAM_Force_embed", "EAM_Force_nl_lds<3"],
+        ("eam", "thread_atom"): ["EAM_Force_thread_atom<1", "EAM_Force_embed", "EAM_Force_thread_atom<3"]}
+
+
+def stats_file(pot, meth):
+    g = glob.glob(os.path.join(F, f"stats_{pot}_{meth}", "**", "out_kernel_stats.csv"), recursive=True)
+    return g[0] if g else None
+
+
+def main():
+    shutil.copy(os.path.join(F, "bench_default.json"), os.path.join(P, "r03_bench_default.json"))
+    for pot, meth in PATHS:
+        f = stats_file(pot, meth)
+        if f:
+            shutil.copy(f, os.path.join(P, f"r03_80_{pot}_{meth}_kernel_stats.csv"))
+    g = glob.glob(os.path.join(F, "stats_loopback_lj", "**", "out_kernel_stats.csv"), recursive=True)
+    if g:
+        shutil.copy(g[0], os.path.join(P, "r03_80_lj_thread_atom_rccl_loopback_kernel_stats.csv"))
+    for name in ("lj20", "lj20_device_timers", "lj40_device_timers", "eam20", "eam40_device_timers", "eam20_thread_atom", "lj20_nl", "eam20_nl", "setfl20", "lj20_pairlist", "sp_lj20", "sp_eam20"):
+        shutil.copy(os.path.join(F, f"comd_hip_{name}_stdout.txt"), os.path.join(P, f"r03_comd_hip_{name}_stdout.txt"))
+    shutil.copy(os.path.join(F, "pmc_summary.json"), os.path.join(P, "r03_pmc_summary.json"))
+    shutil.copy(os.path.join(F, "plain_eam_round2_kernel.json"), os.path.join(P, "r03_bench_eam_round2_kernel.json"))
+    g2 = glob.glob(os.path.join(F, "stats_eam_cta_cell_round2", "**", "out_kernel_stats.csv"), recursive=True)
+    if g2:
+        shutil.copy(g2[0], os.path.join(P, "r03_80_eam_cta_cell_round2_kernel_kernel_stats.csv"))
+    loop = {}
+    for tag in ("plain_lj", "loopback_lj", "loopback_lj_handshake", "plain_eam", "loopback_eam", "loopback_eam_handshake"):
+        d = json.load(open(os.path.join(F, tag + ".json")))
+        loop[tag] = {"ms_per_step": d["ms_per_step"], "force_ms_per_step": d["roofline"]["kernel_ms_per_step"], "value": d["value"], "config": d["config"]}
+    loop["_about"] = ("One GPU, 80^3.  plain: no transport (a rank that is its own neighbour unpacks straight from its send buffers).  loopback: COMD_LOOPBACK_TRANSPORT=1, every halo "
+                      "message and reduction goes through a one-rank RCCL communicator (ncclSend/ncclRecv to itself) with the sized protocol (no handshake, no host sync); "
+                      "loopback_*_handshake: COMD_HALO_HANDSHAKE=1, the exact-size handshake of round 1 (three host syncs per exchange).")
+    json.dump(loop, open(os.path.join(P, "r03_rccl_loopback_bench.json"), "w"), indent=1)
+
+    pmc = json.load(open(os.path.join(F, "pmc_summary.json")))
+
+    def per_launch(tag, ctr, prefixes):
+        d = pmc.get(f"pmc_{tag}_{ctr}", {})
+        tot = 0.0
+        for pre in prefixes:
+            ks = [k for k in d if k.startswith(pre) and ctr in d[k]]
+            if not ks:
+                return None
+            tot += d[max(ks, key=lambda k: d[k][ctr]["launches"])][ctr]["per_launch"]
+        return tot
+
+    traffic = {"_about": "Per-evaluation memory-side traffic of the force kernels from rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE collected in separate runs with "
+                         "--kernel-trace only; both in KiB).  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE under-reports a wide coalesced 16 B/lane stream by exactly 2x on gfx950 "
+                         "and is uncalibrated for other widths; these kernels read through 64-byte scalar loads, 8-byte lane loads and 2-byte list loads, so the fetch side is given raw. "
+                         "WRITE_SIZE is exact for streaming stores.  bench.py reports raw_fetch + write as `traffic`.  Every force kernel of the runs: profiles/r03_pmc_summary.json."}
+    for pot, meth in [("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("eam", "cta_cell"), ("eam", "thread_atom_nl")]:
+        pre = KERN[(pot, meth)]
+        fe, wr = per_launch(f"{pot}_{meth}", "FETCH_SIZE", pre), per_launch(f"{pot}_{meth}", "WRITE_SIZE", pre)
+        if fe is None or wr is None:
+            continue
+        iv = None
+        if f"pmc_{pot}_{meth}_SQ1" in pmc:
+            dd = pmc[f"pmc_{pot}_{meth}_SQ1"]
+            iv = 0.0
+            for pr in pre:
+                ks = [k for k in dd if k.startswith(pr) and "SQ_INSTS_VALU" in dd[k]]
+                iv = iv + dd[max(ks, key=lambda k: dd[k]["SQ_INSTS_VALU"]["launches"])]["SQ_INSTS_VALU"]["per_launch"] if ks and iv is not None else None
+        traffic[f"{pot}/{meth}/80"] = {"kernel": " + ".join(pre), "fetch_KiB": fe, "write_KiB": wr, "algorithmic_bytes": (56 if pot == "lj" else 176) * N,
+                                       **({"insts_valu": iv} if iv else {}),
+                                       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python3 bench.py --pot P --method M --no-variants --steps 10 --warmup 3"}
+    json.dump(traffic, open(os.path.join(P, "r03_traffic.json"), "w"), indent=1)
+
+    d = json.load(open(os.path.join(P, "r03_bench_default.json")))
+    out = ["# Round 3 measurements on MI355X (gfx950, ROCm 7.2) -- final state of the round\n",
+           "Collected by `profiles/r03_collect.sh` in ONE gpurun call (GPU test suite, smoke, bench, comd-hip runs, rocprofv3 passes) and written here by `profiles/r03_summarize.py`.\n",
+           "One GPU, 80^3 unit cells = 2,048,000 Cu atoms, T = 600 K, dt = 1 fs, atoms resident in HBM.  All rows are from one run of `python3 bench.py` "
+           "(20 timed steps after 5 warm-up steps; `profiles/r03_bench_default.json`): the headline configuration is `value`, the others its `variants`.  "
+           "`force ms` = HIP events on the launch stream around every force launch of the timed steps.\n",
+           "| workload | dtype | ms/step | M atom-updates/s | force ms/step | cell slots | round 2 ms/step |", "|---|---|---|---|---|---|---|"]
+    r1 = {"LJ thread_atom": 3.17, "LJ thread_atom_nl": 2.15, "LJ cta_cell": 3.16, "LJ cta_cell_pairlist": 4.74, "EAM cta_cell": 1.74, "EAM thread_atom_nl": 1.98, "EAM thread_atom": 3.67}      # round 2 (profiles/r02_summary.md)
+    rows = [(f"LJ Cu FCC 80^3, thread_atom (headline: BASELINE configs[1])", "f64", d["ms_per_step"], d["value"], d["roofline"]["kernel_ms_per_step"], d["config"]["cell_capacity"], r1["LJ thread_atom"])]
+    for v in d.get("variants", []):
+        if "error" in v:
+            continue
+        key = v["workload"].replace(" Cu FCC 80^3,", "").strip()
+        rows.append((v["workload"], v.get("dtype", "f64"), v["ms_per_step"], v["value"], v["force_ms_per_step"], v.get("cell_capacity", ""), r1.get(key, "")))
+    for w, dt, ms, val, fms, cap, old in rows:
+        out.append(f"| {w} | {dt} | {ms:.3f} | {val / 1e6:.1f} | {fms:.3f} | {cap} | {old} |")
+    rf = d["roofline"]
+    out.append(f"\nHeadline roofline object: kernel `{rf['kernel']}`, {rf['kernel_ms_per_step']:.3f} ms per launch, achieved {rf['achieved']:.1f} GB/s of {rf['peak']:.0f} "
+               f"(frac {rf['frac']:.4f}); fp64 vector model {rf['fp64_vector']['achieved_TFLOPs']:.1f} of {rf['fp64_vector']['peak_TFLOPs']} TFLOP/s (frac {rf['fp64_vector']['frac']:.2f}); "
+               f"traffic {rf['traffic'] and rf['traffic'] / 2 ** 20 or 0:.1f} MiB per launch (raw FETCH_SIZE + WRITE_SIZE) vs {56 * N / 2 ** 20:.1f} MiB algorithmic.\n")
+    cb = d["cpu_baseline"]
+    out.append(f"cpu_baseline (oracle, kind port): {cb['value'] / 1e6:.2f} M atom-updates/s on {cb['cores']} host threads ({cb['sample']}); "
+               f"one core: {cb['one_core']['value'] / 1e6:.3f} M atom-updates/s ({cb['one_core']['sample']}).\n")
+    lp = loop
+    out.append("RCCL on one GPU (`profiles/r03_rccl_loopback_bench.json`): ms/step plain / loopback with the sized protocol / loopback with round 1's handshake: "
+               f"LJ {lp['plain_lj']['ms_per_step']:.3f} / {lp['loopback_lj']['ms_per_step']:.3f} / {lp['loopback_lj_handshake']['ms_per_step']:.3f}; "
+               f"EAM {lp['plain_eam']['ms_per_step']:.3f} / {lp['loopback_eam']['ms_per_step']:.3f} / {lp['loopback_eam_handshake']['ms_per_step']:.3f}.\n")
+    tl = d.get("target_line")
+    if tl and "value" in tl:
+        out.append(f"LJ 256^3 (the BASELINE target line; `target_line` of the same bench run): {tl['ms_per_step']:.1f} ms/step = {tl['value'] / 1e6:.0f} M atom-updates/s, force kernel "
+                   f"{tl['kernel_ms_per_step']:.1f} ms, whole force evaluation {tl['force_evaluation_ms']:.1f} ms, HBM frac {tl['hbm_frac']:.4f}, fp64 model frac {tl['fp64_vector_frac']:.2f}, "
+                   f"device memory {tl['device_memory_GB']}.\n")
+    for v in d.get("variants", []):
+        if "roofline" in v:
+            rr = v["roofline"]
+            out.append(f"{v['workload']} ({v.get('baseline_config', '')}) roofline object: {rr['kernel_ms_per_step']:.3f} ms per force evaluation, achieved {rr['achieved']:.0f} GB/s "
+                       f"(frac {rr['frac']:.4f}), fp64 model frac {rr['fp64_vector']['frac']:.2f}" + (f", VALU issue frac {rr['valu_issue_frac']:.2f}" if 'valu_issue_frac' in rr else "") + ".\n")
+
+    def table(fn, title, cmd):
+        out.append(f"## {title}\n\n`{cmd}` (raw: `profiles/{fn}`)\n")
+        out.append("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
+        for r in list(csv.DictReader(open(os.path.join(P, fn))))[:12]:
+            out.append(f"| {r['Name'].split('(')[0]} | {r['Calls']} | {float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['AverageNs']) / 1e3:.1f} | {r['Percentage']} |")
+        out.append("")
+
+    base = "rocprofv3 --kernel-trace --stats -- python3 bench.py --pot {} --method {} --no-cpu-baseline --no-variants --steps 100 --warmup 10"
+    for pot, meth in PATHS:
+        fn = f"r03_80_{pot}_{meth}_kernel_stats.csv"
+        if os.path.exists(os.path.join(P, fn)):
+            table(fn, f"{pot.upper()} 80^3 {meth}", base.format(pot, meth))
+    fn = "r03_80_lj_thread_atom_rccl_loopback_kernel_stats.csv"
+    if os.path.exists(os.path.join(P, fn)):
+        table(fn, "LJ 80^3 thread_atom through the RCCL loopback (ncclDevKernel rows = the three grouped send/recv per exchange)",
+              "COMD_LOOPBACK_TRANSPORT=1 rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline --no-variants --steps 50 --warmup 5")
+    out.append("## PMC passes (separate runs, `--pmc ...` with `--kernel-trace` only; per-launch averages in `profiles/r03_pmc_summary.json`)\n")
+    out.append("| force path | fetched MiB / evaluation | written MiB | algorithmic MiB |\n|---|---|---|---|")
+    for k, v in traffic.items():
+        if k != "_about":
+            out.append(f"| {k} ({v['kernel']}) | {v['fetch_KiB'] / 1024:.1f} | {v['write_KiB'] / 1024:.1f} | {v['algorithmic_bytes'] / 2 ** 20:.1f} |")
+    out.append("")
+    for tag, names in (("lj_thread_atom", ["LJ_Force_thread_atom<false, true>"]), ("eam_cta_cell", ["EAM_Force_cta_brick<1, true, false>", "EAM_Force_cta_brick<3, true, false>"])):
+        for nm in names:
+            sq = {}
+            for grp in ("SQ1", "SQ2", "TCC"):
+                for k, v in pmc.get(f"pmc_{tag}_{grp}", {}).items():
+                    if k.startswith(nm):
+                        sq.update({c: x["per_launch"] for c, x in v.items()})
+            if sq:
+                wc = sq.get("SQ_WAVE_CYCLES", 0)
+                line = f"* `{nm}` per launch: " + ", ".join(f"{c} {x:.3g}" for c, x in sorted(sq.items()))
+                if wc:
+                    line += f" -- VALU instructions per atom {sq.get('SQ_INSTS_VALU', 0) / N:.0f}; wave cycles spent waiting (SQ_WAIT_ANY) {100 * sq.get('SQ_WAIT_ANY', 0) / wc:.0f} %"
+                if sq.get("TCC_HIT_sum"):
+                    line += f"; L2 hit rate {100 * sq['TCC_HIT_sum'] / (sq['TCC_HIT_sum'] + sq['TCC_MISS_sum']):.1f} %"
+                out.append(line)
+    out.append("")
+    open(os.path.join(P, "r03_summary.md"), "w").write("\n".join(out))
+    print("\n".join(out[4:20]))
+
+
+if __name__ == "__main__":
+    main()
