@@ -392,6 +392,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
                     sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1] };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
+   if (sim->statusEvent) (void)hipEventDestroy((hipEvent_t)sim->statusEvent);
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
    if (sim->interior_stream) HIP_CHECK(hipStreamDestroy(S(sim->interior_stream)));
@@ -420,6 +421,19 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
       fprintf(stderr, "\n");
       exit(-1);
    }
+}
+
+extern "C" void comdPollStatus(SimGpu* sim, comdStream_t stream, const char* where)
+{
+   int* mirror = (int*)(sim->pinned + 32);               // four ints of the 64-real_t pinned block, away from the energy words
+   if (sim->statusEvent) {
+      if (hipEventQuery((hipEvent_t)sim->statusEvent) != hipSuccess) return;       // the previous mirror has not landed yet: look again next step
+      if (mirror[0] | mirror[1] | mirror[2] | mirror[3]) comdCheckStatus(sim, where);
+   } else {
+      hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); sim->statusEvent = (void*)e;
+   }
+   HIP_CHECK(hipMemcpyAsync(mirror, sim->status, 4 * sizeof(int), hipMemcpyDeviceToHost, S(stream)));
+   HIP_CHECK(hipEventRecord((hipEvent_t)sim->statusEvent, S(stream)));
 }
 
 extern "C" int comdReadDeviceInt(const int* d_ptr, comdStream_t stream)

@@ -267,6 +267,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
       iBox = uniform(sBox[hc]); ownStart = uniform(sOff[hc]); ni = uniform(sOff[hc + 1]) - ownStart;
    };
    Pre3 pre;
+   pre.lo = make_uint4(0u, 0u, 0u, 0u); pre.hi = pre.lo; pre.n = 0; pre.f0x = pre.f0y = pre.f0z = R(0.0);
    if (STEP == 3 && fits && wave < nSel) { int iBox, os, ni, yh, zh; cellHeader(wave, iBox, os, ni, yh, zh); fetch3(iBox, ni, 0, pre); }
    for (int pick = wave; pick < nSel; pick += nWaves) {
       int iBox, ownStart, ni, yh, zh;

@@ -31,6 +31,9 @@ double timestep(SimFlat* s, int nSteps, real_t dt)
       computeForce(s);
       stopTimer(computeForceTimer);
       comdSetEnergyNeeded(&s->gpu, 1);
+      /* device status words (cell overflow, lost atom, message overflow, row overflow) of the step BEFORE, without a synchronisation: a run with a
+       * dropped atom stops a step or two later (round 2: at the next energy read, up to printRate steps on) */
+      comdPollStatus(&s->gpu, s->gpu.boundary_stream, "timestep");
 
       startTimer(velocityTimer);
       if (ii == nSteps - 1) advanceVelocity(s, 0.5 * dt);

@@ -175,6 +175,7 @@ typedef struct SimGpu {
                                         * once -- same e[], dfEmbed[] after the pair of calls, one launch fewer */
    /* scan scratch of the reference-side adapter (include/comd_hip_shim.h comdShimOffsets): the reference's per-face partial_sums arrays hold nCells ints,
     * the scans here need nCells + 1; grown on demand, freed by DestroyGpu; the library itself never touches it */
+   void*        statusEvent;           /* comdPollStatus: recorded behind the last status mirror (pinned[32..35]), NULL before the first poll */
    int*         adapterScan;
    int          adapterScanCap;
    /* fields the reference's host code assigns (timestep.c:229-236); kept so that those statements compile, not read by the library */
@@ -249,6 +250,10 @@ void  comdMemcpyAsync(void* dst, const void* src, long bytes, int kind, comdStre
 void  comdDeviceMemset(void* p, int value, long bytes);
 /* check SimGpu.status; prints and exit(-1)s on cell overflow / lost atoms (DEBUG asserts of gpu_redistribute.h:145-154) */
 void comdCheckStatus(SimGpu* sim, const char* where);
+/* the same without waiting for the device: every call looks at the status words mirrored into pinned memory by the call BEFORE (an asynchronous
+ * 16-byte copy on `stream`, a step old by then) and enqueues the next mirror; a non-zero word goes to comdCheckStatus (which prints and exits).
+ * timestep() calls it once per step: a dropped atom or an overflowing cell stops the run one or two steps later, not at the next energy read. */
+void comdPollStatus(SimGpu* sim, comdStream_t stream, const char* where);
 
 /* ---- force: gpu_kernels.h:13-24 ------------------------------------------------------------ */
 /* ljForceGpu(SimGpu*, interpolation, num_cells, cells_list, plcutoff, method), gpu_kernels.cu:69-122.

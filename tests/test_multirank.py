@@ -108,9 +108,9 @@ def test_message_that_outgrows_its_agreed_size_stops_the_run():
 
 @pytest.mark.gpu
 def test_bench_reports_what_rccl_saw_and_maps_one_copy_of_it():
-    """bench.py imports torch (for the gloo control plane) before libcomd_hip.so, so two builds of librccl are within reach: torch's
-    bundled one and /opt/rocm's.  Exactly one may end up mapped, the communicator must report the launched rank count, and the line must
-    carry both facts (rccl_ranks, librccl) so that a SCALE record shows what carried the halo messages."""
+    """bench.py forms the communicator the way comd-hip does (comdCommInitFromEnv; no torch in the rank process since round 3), so exactly ONE librccl and
+    ONE libamdhip64 -- the copies under /opt/rocm that libcomd_hip.so was linked against -- may be mapped; the communicator must report the launched
+    rank count, and the line must carry these facts so that a SCALE record shows what carried the halo messages."""
     import json
     env = dict(os.environ, COMD_LOOPBACK_TRANSPORT="1", MASTER_PORT=str(_free_port()))
     proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--nx", "20", "--steps", "3", "--warmup", "1",
@@ -119,7 +119,8 @@ def test_bench_reports_what_rccl_saw_and_maps_one_copy_of_it():
     line = json.loads(proc.stdout.strip().splitlines()[-1])
     cfg = line["config"]
     assert cfg["transport"] == "rccl-loopback" and cfg["rccl_ranks"] == 1 and cfg["rank_devices"] == [0]
-    assert len(cfg["librccl"]) == 1, cfg["librccl"]
+    assert len(cfg["librccl"]) == 1 and len(cfg["libamdhip64"]) == 1, (cfg["librccl"], cfg["libamdhip64"])
+    assert all(os.path.realpath(p).startswith("/opt/rocm") for p in cfg["librccl"] + cfg["libamdhip64"]) and cfg["one_rocm_runtime_on_every_rank"]
     assert "measured" not in line
 
 
