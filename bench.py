@@ -51,8 +51,8 @@ FORCE_FLOP_LISTED = {"lj": 2350 * 8 + 550 * 25}
 # Verlet lists (skin 10 %): ~732 (LJ) / ~57 (EAM) listed neighbours take the place of the stencil candidates
 FORCE_FLOP_NL = {"lj": 732 * 8 + 550 * 25, "eam": 2 * (57 * 8 + 42 * 70)}
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0                 # wave-instructions/s the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction
-KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs", ("lj", "cta_cell_pairlist"): "LJ_Force_cta_cell",
-               ("eam", "thread_atom"): "EAM_Force_thread_atom", ("eam", "cta_cell"): "EAM_Force_cta_cell", ("eam", "thread_atom_nl"): "EAM_Force_nl_lds"}
+KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell_boxes", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs", ("lj", "cta_cell_pairlist"): "LJ_Force_cta_cell",
+               ("eam", "thread_atom"): "EAM_Force_thread_atom", ("eam", "cta_cell"): "EAM_Force_cta_brick<1> + <3>", ("eam", "thread_atom_nl"): "EAM_Force_nl_lds"}
 
 
 def parse():
