@@ -390,7 +390,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
-                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1] };
+                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1], sim->lj_pot.packedF[0], sim->lj_pot.packedF[1] };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->statusEvent) (void)hipEventDestroy((hipEvent_t)sim->statusEvent);
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
@@ -494,6 +494,22 @@ static void ljBoxMargins(const SimGpu* sim, real_t rc2, real_t* rc2Box, real_t* 
    *grow = (real_t)(1.0 + rel);
 }
 
+// The list build of thread_atom (LJ_WaveCandidates) makes the same test in SINGLE precision on positions relative to the corner of the local domain
+// (LJ_PackPositions): the conversion moves a coordinate by half an ulp of the largest relative coordinate (local domain + one halo cell on either side),
+// the arithmetic of the box distance is good to ~1e-6 relative -- the cutoff is pushed out by 1e-5 relative + eight such ulps per axis.
+static void ljBoxMarginsF(const SimGpu* sim, real_t rc2, float* rc2Box, float* grow)
+{
+   const double rel = 1e-5, eps = 1.1920929e-07;
+   double big = 0.0;
+   for (int a = 0; a < 3; ++a) {
+      const double ext = (double)sim->boxes.localMax[a] - (double)sim->boxes.localMin[a] + 2.0 / sim->boxes.invBoxSize[a];
+      if (ext > big) big = ext;
+   }
+   const double rc = sqrt((double)rc2) * (1.0 + rel) + 8.0 * 1.7320508 * eps * big;
+   *rc2Box = (float)(rc * rc * (1.0 + 2.0 * eps));
+   *grow = (float)(1.0 + rel);
+}
+
 // thread_atom (the BASELINE-named kernel): candidate lists, then the force kernel
 static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int* cells_list, comdStream_t stream)
 {
@@ -527,7 +543,7 @@ static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int*
       // ~250 B of list per atom (18 GB at 256^3) + the packed records (2.9 GB each): when that does not fit what the device has free (keeping 2 GB
       // for everything allocated later), or the 32-bit offsets cannot reach the records, this simulation walks the stencil as round 1 did
       const double listBytes = (double)sim->boxes.nLocalBoxes * lj->waveCandWaves * lj->waveCandCap * 4.0 + (double)sim->boxes.nLocalBoxes * lj->waveCandWaves * 8.0
-                               + (sim->interior_stream ? 2.0 : 1.0) * (double)sim->boxes.nTotalBoxes * lj->packedCap * sizeof(LjPos4);
+                               + (sim->interior_stream ? 2.0 : 1.0) * (double)sim->boxes.nTotalBoxes * lj->packedCap * (sizeof(LjPos4) + sizeof(float4));
       size_t freeB = 0, totalB = 0;
       HIP_CHECK(hipMemGetInfo(&freeB, &totalB));
       if ((double)sim->boxes.nTotalBoxes * lj->packedCap * sizeof(LjPos4) >= 4294967296.0) lj->packedCap = -1;     // no lists for this simulation
@@ -546,15 +562,19 @@ static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int*
       // the force may be split over two streams (-a 1: interior cells while the halo exchange is in flight, boundary cells after it):
       // each stream packs the positions it is about to read into its own array
       const int which = (cells_list && stream != sim->interior_stream) ? 1 : 0;
-      if (!lj->packedR[which]) lj->packedR[which] = dalloc<real_t>((size_t)sim->boxes.nTotalBoxes * lj->packedCap * 4, false);
-      wl.cand = lj->waveCand; wl.pos = (const LjPos4*)lj->packedR[which]; wl.count = (int2*)lj->waveCandCount;
+      if (!lj->packedR[which]) {
+         lj->packedR[which] = dalloc<real_t>((size_t)sim->boxes.nTotalBoxes * lj->packedCap * 4, false);
+         lj->packedF[which] = dalloc<float>((size_t)sim->boxes.nTotalBoxes * lj->packedCap * 4, false);
+      }
+      wl.cand = lj->waveCand; wl.pos = (const LjPos4*)lj->packedR[which]; wl.posF = (const float4*)lj->packedF[which]; wl.count = (int2*)lj->waveCandCount;
       wl.candCap = lj->waveCandCap; wl.wavesMax = lj->waveCandWaves; wl.capP = lj->packedCap;
-      ljBoxMargins(sim, a.rc2, &wl.rc2Box, &wl.grow);
+      ljBoxMarginsF(sim, a.rc2, &wl.rc2BoxF, &wl.growF);
       // interior cells never have a halo cell in their stencil, and the halo cells are being filled while they run
       const int packCells = (cells_list && stream == sim->interior_stream) ? sim->boxes.nLocalBoxes : sim->boxes.nTotalBoxes;
       ForceTimer aux(sim, S(stream), 1);               // the list build of this evaluation (bench.py: force_evaluation_ms = kernel + this)
       hipLaunchKernelGGL(LJ_PackPositions, dim3((unsigned)ceilDiv((long)packCells * lj->packedCap, 256)), dim3(256), 0, S(stream),
-                         a.rx, a.ry, a.rz, a.nAtoms, (LjPos4*)lj->packedR[which], a.cap, lj->packedCap, packCells, a.rc2);
+                         a.rx, a.ry, a.rz, a.nAtoms, (LjPos4*)lj->packedR[which], (float4*)lj->packedF[which], a.cap, lj->packedCap, packCells, a.rc2,
+                         sim->boxes.localMin[0], sim->boxes.localMin[1], sim->boxes.localMin[2]);
       hipLaunchKernelGGL(LJ_WaveCandidates, dim3((unsigned)ceilDiv(num_cells, 4)), dim3(256), 0, S(stream), a, wl, w);
    }
    ForceTimer timer(sim, S(stream));                     // the force kernel proper (bench.py's roofline line; rocprof must agree with it)

@@ -77,7 +77,8 @@ __device__ __forceinline__ void ljCellLoop(const LjArgs& a, int jBox, real_t xi,
 // 5-sigma LJ Cu), but an atom further than the cutoff from the bounding box of those 64 atoms is a miss for every lane.
 // LJ_WaveCandidates drops them before the force kernel runs: one wave per (cell, 64-slot chunk), 64 stencil atoms per trip (one
 // per lane), point-to-box distance, ballot + mbcnt compaction, global slots appended in stencil order -- the cell's own atoms
-// first, so the order of every lane's sum is that of the plain stencil walk and the forces are bit-identical to it.
+// first, so the order of every lane's sum in a FULL wave is that of the plain stencil walk and its forces are bit-identical to it (a tail wave
+// deals its list to replicas in parts other than the walk's: same pairs, partial sums in another order).
 // The lists are rebuilt by every force call (no skin, nothing carried over): a pruning device, not a Verlet list.
 // A list that would not fit its row is marked -1 and the force kernel walks the stencil for that wave.
 // One candidate as the force kernel fetches it: the fourth field is rc^2, the same in every record.  Comparing r^2 against the record's copy
@@ -90,7 +91,8 @@ struct LjWaveLists {
    int2*     __restrict__ count;       // [nLocalCells * wavesMax] {candidates of the own cell, all candidates}; y < 0: no list
    int candCap, wavesMax;
    int capP;                           // slots per cell in pos (<= cap: the waves the lists are laid out for); a stencil with a fuller cell gets no lists
-   real_t rc2Box, grow;                // rc^2 and a factor on the half widths, each with a margin for the rounding of the box distance
+   const float4* __restrict__ posF;    // [nTotalCells * capP] the same records in single precision, relative to the corner of the local domain (the list build's copy)
+   float rc2BoxF, growF;               // rc^2 and a factor on the half widths of the list build's fp32 boxes, each with a margin for the rounding of the box distance
 };
 
 // a list entry is the BYTE offset of the candidate in the packed position array (32 bits: base + zero-extended offset is the s_load
@@ -139,7 +141,7 @@ __device__ __forceinline__ void ljListLoop(const LjArgs& a, const LjPos4* __rest
 // x, y, z of every occupied slot side by side, so that one scalar load fetches a candidate
 __global__ __launch_bounds__(256)
 void LJ_PackPositions(const real_t* __restrict__ rx, const real_t* __restrict__ ry, const real_t* __restrict__ rz, const int* __restrict__ nAtoms,
-                      LjPos4* __restrict__ pos, int cap, int capP, int nCells, real_t rc2)
+                      LjPos4* __restrict__ pos, float4* __restrict__ posF, int cap, int capP, int nCells, real_t rc2, real_t ox, real_t oy, real_t oz)
 {
    const long t = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(t / capP), i = (int)(t - (long)c * capP);
@@ -147,10 +149,17 @@ void LJ_PackPositions(const real_t* __restrict__ rx, const real_t* __restrict__ 
    const size_t o = (size_t)c * cap + i;
    LjPos4 v; v.x = rx[o]; v.y = ry[o]; v.z = rz[o]; v.rc2 = rc2;
    pos[(size_t)c * capP + i] = v;
+   // the same position in single precision, relative to the corner of the local domain: what the LIST BUILD tests against its boxes (a pruning
+   // test with a margin for exactly this rounding; the force kernel decides on the fp64 record)
+   posF[(size_t)c * capP + i] = make_float4((float)(v.x - ox), (float)(v.y - oy), (float)(v.z - oz), 0.0f);
 }
 
 __device__ __forceinline__ real_t waveMinR(real_t v) { for (int d = 1; d < 64; d <<= 1) v = minR(v, __shfl_xor(v, d)); return v; }
 __device__ __forceinline__ real_t waveMaxR(real_t v) { for (int d = 1; d < 64; d <<= 1) v = maxR(v, __shfl_xor(v, d)); return v; }
+#ifndef COMD_SINGLE
+__device__ __forceinline__ float waveMinR(float v) { for (int d = 1; d < 64; d <<= 1) v = __builtin_fminf(v, __shfl_xor(v, d)); return v; }
+__device__ __forceinline__ float waveMaxR(float v) { for (int d = 1; d < 64; d <<= 1) v = __builtin_fmaxf(v, __shfl_xor(v, d)); return v; }
+#endif
 
 __device__ __forceinline__ double uniformR(double v)
 {
@@ -162,7 +171,8 @@ __device__ __forceinline__ float uniformR(float v) { return __int_as_float(__bui
 
 // One wave per cell builds the lists of all of the cell's waves in one sweep over the stencil (the sweep is L2 traffic: one per list made
 // this kernel bandwidth-bound at 0.39 ms).  Boxes are held as centre + half width: the distance of a point to the box along an axis is
-// max(0, |x - c| - h).
+// max(0, |x - c| - h).  The whole test runs in SINGLE precision on the float4 records of LJ_PackPositions (one 16-byte load per stencil atom
+// instead of three 8-byte ones, fp32 VALU instructions at twice the fp64 rate); w.rc2BoxF and w.growF carry the margin that covers it.
 #define LJ_LIST_CHUNKS 4                      // lists built per sweep (cells of up to 256 atoms need one sweep)
 #define LJ_LIST_TRIPS 3                       // 64-atom trips of a stencil cell held in registers (and prefetched a cell ahead)
 __global__ __launch_bounds__(256)
@@ -185,73 +195,75 @@ void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
       if (lane < nChunks) w.count[iBox * w.wavesMax + lane] = make_int2(0, -1);
       return;
    }
+   const float4* __restrict__ P = w.posF;
+   const unsigned capP = (unsigned)w.capP;
 
    for (int c0 = 0; c0 < nChunks; c0 += LJ_LIST_CHUNKS) {
-      real_t cx[LJ_LIST_CHUNKS], cy[LJ_LIST_CHUNKS], cz[LJ_LIST_CHUNKS], hx[LJ_LIST_CHUNKS], hy[LJ_LIST_CHUNKS], hz[LJ_LIST_CHUNKS];
+      float cx[LJ_LIST_CHUNKS], cy[LJ_LIST_CHUNKS], cz[LJ_LIST_CHUNKS], hx[LJ_LIST_CHUNKS], hy[LJ_LIST_CHUNKS], hz[LJ_LIST_CHUNKS];
       int n[LJ_LIST_CHUNKS], nSelf[LJ_LIST_CHUNKS];
 #pragma unroll
       for (int c = 0; c < LJ_LIST_CHUNKS; ++c) {
          n[c] = 0; nSelf[c] = 0;
-         cx[c] = cy[c] = cz[c] = hx[c] = hy[c] = hz[c] = R(0.0);
+         cx[c] = cy[c] = cz[c] = hx[c] = hy[c] = hz[c] = 0.0f;
          if (c0 + c < nChunks) {
             const int iSlot = (c0 + c) * 64 + lane;
-            const size_t iOff = (size_t)iBox * a.cap + (iSlot < ni ? iSlot : ni - 1);      // idle lanes shadow the cell's last atom (it is in the last chunk)
-            const real_t xi = a.rx[iOff], yi = a.ry[iOff], zi = a.rz[iOff];
-            const real_t xlo = waveMinR(xi), xhi = waveMaxR(xi), ylo = waveMinR(yi), yhi = waveMaxR(yi), zlo = waveMinR(zi), zhi = waveMaxR(zi);
-            // half widths rounded up by an ulp-sized factor: the box may only grow
-            cx[c] = uniformR(R(0.5) * (xlo + xhi)); hx[c] = uniformR(R(0.5) * (xhi - xlo) * w.grow);
-            cy[c] = uniformR(R(0.5) * (ylo + yhi)); hy[c] = uniformR(R(0.5) * (yhi - ylo) * w.grow);
-            cz[c] = uniformR(R(0.5) * (zlo + zhi)); hz[c] = uniformR(R(0.5) * (zhi - zlo) * w.grow);
+            const float4 q = P[(unsigned)iBox * capP + (unsigned)(iSlot < ni ? iSlot : ni - 1)];      // idle lanes shadow the cell's last atom (it is in the last chunk)
+            const float xlo = waveMinR(q.x), xhi = waveMaxR(q.x), ylo = waveMinR(q.y), yhi = waveMaxR(q.y), zlo = waveMinR(q.z), zhi = waveMaxR(q.z);
+            // half widths rounded up by a factor: the box may only grow
+            cx[c] = uniformR(0.5f * (xlo + xhi)); hx[c] = uniformR(0.5f * (xhi - xlo) * w.growF);
+            cy[c] = uniformR(0.5f * (ylo + yhi)); hy[c] = uniformR(0.5f * (yhi - ylo) * w.growF);
+            cz[c] = uniformR(0.5f * (zlo + zhi)); hz[c] = uniformR(0.5f * (zhi - zlo) * w.growF);
          }
       }
+      const int nC = nChunks - c0 < LJ_LIST_CHUNKS ? nChunks - c0 : LJ_LIST_CHUNKS;
       // cells of up to 64 * LJ_LIST_TRIPS atoms in one round of 64-atom trips, loaded one cell ahead of the tests
-      real_t x[LJ_LIST_TRIPS], y[LJ_LIST_TRIPS], z[LJ_LIST_TRIPS], xn[LJ_LIST_TRIPS], yn[LJ_LIST_TRIPS], zn[LJ_LIST_TRIPS];
+      float4 q[LJ_LIST_TRIPS], qn[LJ_LIST_TRIPS];
       int jBox = __builtin_amdgcn_readlane(myBox, 0), nj = __builtin_amdgcn_readlane(myCount, 0);
 #pragma unroll
       for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
          const int j = 64 * t + lane;
-         if (64 * t < nj) { const size_t o = (size_t)jBox * a.cap + (j < nj ? j : 0); xn[t] = a.rx[o]; yn[t] = a.ry[o]; zn[t] = a.rz[o]; }
+         if (64 * t < nj) qn[t] = P[(unsigned)jBox * capP + (unsigned)(j < nj ? j : 0)];
       }
       for (int k = 0; k < 27; ++k) {
          const int jBoxNow = jBox, njNow = nj;
 #pragma unroll
-         for (int t = 0; t < LJ_LIST_TRIPS; ++t) { x[t] = xn[t]; y[t] = yn[t]; z[t] = zn[t]; }
+         for (int t = 0; t < LJ_LIST_TRIPS; ++t) q[t] = qn[t];
          if (k + 1 < 27) {
             jBox = __builtin_amdgcn_readlane(myBox, k + 1); nj = __builtin_amdgcn_readlane(myCount, k + 1);
 #pragma unroll
             for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
                const int j = 64 * t + lane;
-               if (64 * t < nj) { const size_t o = (size_t)jBox * a.cap + (j < nj ? j : 0); xn[t] = a.rx[o]; yn[t] = a.ry[o]; zn[t] = a.rz[o]; }
+               if (64 * t < nj) qn[t] = P[(unsigned)jBox * capP + (unsigned)(j < nj ? j : 0)];
             }
          }
-         const size_t base = (size_t)jBoxNow * a.cap;
+         const unsigned base = (unsigned)jBoxNow * capP;
          for (int j0 = 0; j0 < njNow; j0 += 64 * LJ_LIST_TRIPS) {
             if (j0 > 0) {                                  // fuller cells: the later rounds are loaded on the spot
 #pragma unroll
                for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
                   const int j = j0 + 64 * t + lane;
-                  const size_t o = base + (j < njNow ? j : 0);
-                  x[t] = a.rx[o]; y[t] = a.ry[o]; z[t] = a.rz[o];
+                  q[t] = P[base + (unsigned)(j < njNow ? j : 0)];
                }
             }
 #pragma unroll
             for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
-               const int j = j0 + 64 * t + lane;
-               if (j0 + 64 * t >= njNow) break;
-               const unsigned entry = (unsigned)(((size_t)jBoxNow * w.capP + j) * sizeof(LjPos4));
+               const int rem = njNow - (j0 + 64 * t);             // stencil atoms this trip still has (wave-uniform)
+               if (rem <= 0) break;
+               const unsigned long long valid = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+               const unsigned entry = (base + (unsigned)(j0 + 64 * t + lane)) * (unsigned)sizeof(LjPos4);
 #pragma unroll
                for (int c = 0; c < LJ_LIST_CHUNKS; ++c) {
-                  if (c0 + c >= nChunks) continue;                // (wave-uniform)
-                  const real_t dx = maxR(R(0.0), absR(x[t] - cx[c]) - hx[c]);
-                  const real_t dy = maxR(R(0.0), absR(y[t] - cy[c]) - hy[c]);
-                  const real_t dz = maxR(R(0.0), absR(z[t] - cz[c]) - hz[c]);
-                  const bool keep = j < njNow && dx*dx + dy*dy + dz*dz <= w.rc2Box;
-                  const unsigned long long mask = __ballot(keep);
+                  if (c >= nC) break;                             // (wave-uniform)
+                  const float dx = __builtin_fmaxf(0.0f, __builtin_fabsf(q[t].x - cx[c]) - hx[c]);
+                  const float dy = __builtin_fmaxf(0.0f, __builtin_fabsf(q[t].y - cy[c]) - hy[c]);
+                  const float dz = __builtin_fmaxf(0.0f, __builtin_fabsf(q[t].z - cz[c]) - hz[c]);
+                  // the compare's mask IS the ballot; lanes past the cell's last atom (they re-read its slot 0) are cleared on the scalar side
+                  const unsigned long long mask = __ballot(dx*dx + dy*dy + dz*dz <= w.rc2BoxF) & valid;
                   // no early-out on a full row: the count keeps running (a row that ends up too long is marked at the end), the store is
                   // what is guarded -- nine independent test -> ballot -> count -> store chains per cell for the scheduler to interleave
-                  const int pos = n[c] + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0u));
-                  unsigned* __restrict__ L = w.cand + (size_t)(iBox * w.wavesMax + c0 + c) * w.candCap;
-                  if (keep && pos < w.candCap) L[pos] = entry;
+                  const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n[c]));
+                  char* __restrict__ L = (char*)(w.cand + (size_t)(iBox * w.wavesMax + c0 + c) * w.candCap);
+                  if (__builtin_amdgcn_inverse_ballot_w64(mask) && pos < (unsigned)w.candCap) *(unsigned*)(L + (pos << 2)) = entry;
                   n[c] += __popcll(mask);
                }
             }

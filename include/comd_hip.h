@@ -59,6 +59,8 @@ typedef struct LjPotentialGpu {
    int       packedCap;                /* slots per cell in packedR: the fullest cell seen at allocation + 16, at most maxAtoms; -1: no lists (the array would pass 4 GiB) */
    real_t*   packedR[2];               /* device [nTotalBoxes * packedCap][4]: {x, y, z, cutoff^2} of the occupied slots, refreshed by every thread_atom
                                         * force call; [1] is used by calls on a stream other than interior_stream when the force is split (-a 1) */
+   float*    packedF[2];               /* device [nTotalBoxes * packedCap][4]: the same positions in single precision, relative to the corner of the local domain:
+                                        * what the list build tests against its boxes (16 bytes per stencil atom instead of 24, fp32 arithmetic) */
 } LjPotentialGpu;
 
 /* gpu_types.h:60-69: cubic spline in r^2 (-P, `spline` argument of eamForce*Gpu): coefficients {a,b,c,d} per table interval,

@@ -146,6 +146,22 @@ def test_lj_wave_candidate_lists_and_their_fallbacks(gpu, orc, monkeypatch, env)
         assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
 
 
+def test_lj_wave_candidate_lists_do_not_lose_a_pair(gpu, monkeypatch):
+    """The list build prunes in single precision on positions relative to the corner of the local domain, with a margin for that rounding
+    (comd_device.hip ljBoxMarginsF); the force kernel decides every pair on the fp64 records.  With the lists and with the plain 27-cell
+    walk the forces may differ by the order of a tail wave's partial sums (1e-14 eV/A here); a pair lost at the cutoff would be a jump
+    of 2e-5 eV/A (the LJ force is not shifted) -- on a long box (coordinates up to ~250 A, where a float ulp is 1.5e-5 A) with a strongly
+    disturbed lattice."""
+    out = []
+    for prune in ("1", "0"):
+        monkeypatch.setenv("COMD_LJ_PRUNE", prune)
+        with gpu.Simulation(_args((70, 7, 7), 0, 0.2, "thread_atom")) as sim:
+            sim.step(2)
+            out.append((sim.gather(2).copy(), sim.gather(3).copy()))
+    assert np.abs(out[0][0] - out[1][0]).max() < 1e-10 and np.abs(out[0][1] - out[1][1]).max() < 1e-12
+    assert (np.abs(out[0][0] - out[1][0]).max(axis=1) == 0).mean() > 0.8        # the full waves add in the walk's order
+
+
 @pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("case", ["eam_6_delta", "lj_8_delta"])
 def test_reference_recorded_forces(gpu, case, method):
