@@ -174,7 +174,8 @@ __device__ __forceinline__ float uniformR(float v) { return __int_as_float(__bui
 // max(0, |x - c| - h).  The whole test runs in SINGLE precision on the float4 records of LJ_PackPositions (one 16-byte load per stencil atom
 // instead of three 8-byte ones, fp32 VALU instructions at twice the fp64 rate); w.rc2BoxF and w.growF carry the margin that covers it.
 #define LJ_LIST_CHUNKS 4                      // lists built per sweep (cells of up to 256 atoms need one sweep)
-#define LJ_LIST_TRIPS 3                       // 64-atom trips of a stencil cell held in registers (and prefetched a cell ahead)
+#define LJ_LIST_TRIPS 3                       // 64-atom trips of a stencil cell held in registers
+#define LJ_LIST_BATCH 3                       // stencil cells loaded together (27 = 9 batches)
 __global__ __launch_bounds__(256)
 void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
 {
@@ -216,61 +217,60 @@ void LJ_WaveCandidates(LjArgs a, LjWaveLists w, int wavesPerCell)
          }
       }
       const int nC = nChunks - c0 < LJ_LIST_CHUNKS ? nChunks - c0 : LJ_LIST_CHUNKS;
-      // cells of up to 64 * LJ_LIST_TRIPS atoms in one round of 64-atom trips, loaded one cell ahead of the tests
-      float4 q[LJ_LIST_TRIPS], qn[LJ_LIST_TRIPS];
-      int jBox = __builtin_amdgcn_readlane(myBox, 0), nj = __builtin_amdgcn_readlane(myCount, 0);
+      // The stencil in batches of LJ_LIST_BATCH cells: the loads of a batch (up to 64 * LJ_LIST_TRIPS atoms per cell) are issued together, behind
+      // the list stores of the batch before.  The stores sit in masked blocks, so hipcc can only wait for the loads with vmcnt(0), which waits
+      // for those stores as well: one such stop per BATCH (nine per wave), where a cell-by-cell sweep with the next cell prefetched made 27.
+      for (int k0 = 0; k0 < 27; k0 += LJ_LIST_BATCH) {
+         float4 q[LJ_LIST_BATCH][LJ_LIST_TRIPS];
+         int jb[LJ_LIST_BATCH], njb[LJ_LIST_BATCH];
 #pragma unroll
-      for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
-         const int j = 64 * t + lane;
-         if (64 * t < nj) qn[t] = P[(unsigned)jBox * capP + (unsigned)(j < nj ? j : 0)];
-      }
-      for (int k = 0; k < 27; ++k) {
-         const int jBoxNow = jBox, njNow = nj;
-#pragma unroll
-         for (int t = 0; t < LJ_LIST_TRIPS; ++t) q[t] = qn[t];
-         if (k + 1 < 27) {
-            jBox = __builtin_amdgcn_readlane(myBox, k + 1); nj = __builtin_amdgcn_readlane(myCount, k + 1);
+         for (int b = 0; b < LJ_LIST_BATCH; ++b) {
+            jb[b] = __builtin_amdgcn_readlane(myBox, k0 + b); njb[b] = __builtin_amdgcn_readlane(myCount, k0 + b);
 #pragma unroll
             for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
                const int j = 64 * t + lane;
-               if (64 * t < nj) qn[t] = P[(unsigned)jBox * capP + (unsigned)(j < nj ? j : 0)];
+               if (64 * t < njb[b]) q[b][t] = P[(unsigned)jb[b] * capP + (unsigned)(j < njb[b] ? j : 0)];
             }
          }
-         const unsigned base = (unsigned)jBoxNow * capP;
-         for (int j0 = 0; j0 < njNow; j0 += 64 * LJ_LIST_TRIPS) {
-            if (j0 > 0) {                                  // fuller cells: the later rounds are loaded on the spot
+#pragma unroll
+         for (int b = 0; b < LJ_LIST_BATCH; ++b) {
+            const int njNow = njb[b];
+            const unsigned base = (unsigned)jb[b] * capP;
+            for (int j0 = 0; j0 < njNow; j0 += 64 * LJ_LIST_TRIPS) {
+               if (j0 > 0) {                               // fuller cells: the later rounds are loaded on the spot
+#pragma unroll
+                  for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
+                     const int j = j0 + 64 * t + lane;
+                     q[b][t] = P[base + (unsigned)(j < njNow ? j : 0)];
+                  }
+               }
 #pragma unroll
                for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
-                  const int j = j0 + 64 * t + lane;
-                  q[t] = P[base + (unsigned)(j < njNow ? j : 0)];
+                  const int rem = njNow - (j0 + 64 * t);          // stencil atoms this trip still has (wave-uniform)
+                  if (rem <= 0) break;
+                  const unsigned long long valid = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
+                  const unsigned entry = (base + (unsigned)(j0 + 64 * t + lane)) * (unsigned)sizeof(LjPos4);
+#pragma unroll
+                  for (int c = 0; c < LJ_LIST_CHUNKS; ++c) {
+                     if (c >= nC) break;                          // (wave-uniform)
+                     const float dx = __builtin_fmaxf(0.0f, __builtin_fabsf(q[b][t].x - cx[c]) - hx[c]);
+                     const float dy = __builtin_fmaxf(0.0f, __builtin_fabsf(q[b][t].y - cy[c]) - hy[c]);
+                     const float dz = __builtin_fmaxf(0.0f, __builtin_fabsf(q[b][t].z - cz[c]) - hz[c]);
+                     // the compare's mask IS the ballot; lanes past the cell's last atom (they re-read its slot 0) are cleared on the scalar side
+                     const unsigned long long mask = __ballot(dx*dx + dy*dy + dz*dz <= w.rc2BoxF) & valid;
+                     // no early-out on a full row: the count keeps running (a row that ends up too long is marked at the end), the store is
+                     // what is guarded
+                     const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n[c]));
+                     char* __restrict__ L = (char*)(w.cand + (size_t)(iBox * w.wavesMax + c0 + c) * w.candCap);
+                     if (__builtin_amdgcn_inverse_ballot_w64(mask) && pos < (unsigned)w.candCap) *(unsigned*)(L + (pos << 2)) = entry;
+                     n[c] += __popcll(mask);
+                  }
                }
             }
+            if (k0 + b == 0) {
 #pragma unroll
-            for (int t = 0; t < LJ_LIST_TRIPS; ++t) {
-               const int rem = njNow - (j0 + 64 * t);             // stencil atoms this trip still has (wave-uniform)
-               if (rem <= 0) break;
-               const unsigned long long valid = rem >= 64 ? ~0ull : (1ull << rem) - 1ull;
-               const unsigned entry = (base + (unsigned)(j0 + 64 * t + lane)) * (unsigned)sizeof(LjPos4);
-#pragma unroll
-               for (int c = 0; c < LJ_LIST_CHUNKS; ++c) {
-                  if (c >= nC) break;                             // (wave-uniform)
-                  const float dx = __builtin_fmaxf(0.0f, __builtin_fabsf(q[t].x - cx[c]) - hx[c]);
-                  const float dy = __builtin_fmaxf(0.0f, __builtin_fabsf(q[t].y - cy[c]) - hy[c]);
-                  const float dz = __builtin_fmaxf(0.0f, __builtin_fabsf(q[t].z - cz[c]) - hz[c]);
-                  // the compare's mask IS the ballot; lanes past the cell's last atom (they re-read its slot 0) are cleared on the scalar side
-                  const unsigned long long mask = __ballot(dx*dx + dy*dy + dz*dz <= w.rc2BoxF) & valid;
-                  // no early-out on a full row: the count keeps running (a row that ends up too long is marked at the end), the store is
-                  // what is guarded -- nine independent test -> ballot -> count -> store chains per cell for the scheduler to interleave
-                  const unsigned pos = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)n[c]));
-                  char* __restrict__ L = (char*)(w.cand + (size_t)(iBox * w.wavesMax + c0 + c) * w.candCap);
-                  if (__builtin_amdgcn_inverse_ballot_w64(mask) && pos < (unsigned)w.candCap) *(unsigned*)(L + (pos << 2)) = entry;
-                  n[c] += __popcll(mask);
-               }
+               for (int c = 0; c < LJ_LIST_CHUNKS; ++c) nSelf[c] = n[c];
             }
-         }
-         if (k == 0) {
-#pragma unroll
-            for (int c = 0; c < LJ_LIST_CHUNKS; ++c) nSelf[c] = n[c];
          }
       }
 #pragma unroll
