@@ -159,6 +159,18 @@ def main():
                     line += f"; L2 hit rate {100 * sq['TCC_HIT_sum'] / (sq['TCC_HIT_sum'] + sq['TCC_MISS_sum']):.1f} %"
                 out.append(line)
     out.append("")
+    # long runs of the shipped executable (profiles/r03_experiments/soak.sh; copied by hand: they are not part of r03_collect.sh)
+    soak = [(f, os.path.join(P, f"r03_soak_{f}.txt")) for f in ("lj80_2000_steps", "eam80_2000_steps", "lj256_100_steps")]
+    if all(os.path.exists(p) for _, p in soak):
+        out.append("## Long runs of `comd-hip --deviceTimers` (`profiles/r03_experiments/soak.sh`, `profiles/r03_soak_*.txt`)\n")
+        out.append("| run | E/atom at step 0 | E/atom at the end | eFinal/eInitial | atom updates per second (loop time) |\n|---|---|---|---|---|")
+        for f, path in soak:
+            txt = open(path).read().splitlines()
+            rows = [l.split() for l in txt if len(l.split()) == 8 and l.split()[0].isdigit()]
+            ratio = [l.split(":")[1].strip() for l in txt if "eFinal/eInitial" in l][0]
+            rate = [l.split(":")[1].split("(")[0].strip() for l in txt if "Atom updates per second" in l][0]
+            out.append(f"| {f} | {rows[0][2]} | {rows[-1][2]} | {ratio} | {rate} |")
+        out.append("")
     open(os.path.join(P, "r03_summary.md"), "w").write("\n".join(out))
     print("\n".join(out[4:20]))
 
