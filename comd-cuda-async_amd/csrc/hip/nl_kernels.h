@@ -296,25 +296,32 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
    real_t* __restrict__ sp = ldsPos;
    (void)groupAtoms;
    const int iBox = a.cells ? a.cells[blockIdx.x] : blockIdx.x;
-   const int i = threadIdx.x;
-   const int ni = a.nAtoms[iBox];
-   const bool active = i < ni;
+   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6);
+   const int ni = uniform(a.nAtoms[iBox]);
+   // A wave owns the atoms 64 wave .. 64 wave + m - 1 of the cell.  An under-filled wave (the tail of a cell: 20 of 64 lanes at 148 atoms, and its
+   // instruction stream is as long as a full wave's) replicates its atoms G times across the lanes: replica g walks the rows g, g + G, ... of each
+   // list, the partial sums meet through ds_bpermute at the end.  A full wave is the case G = 1.
+   const int m = ni - 64 * wave < 64 ? (ni - 64 * wave > 0 ? ni - 64 * wave : 0) : 64;
+   const int G = (m > 0 && m <= 32) ? (64 / m < 4 ? 64 / m : 4) : 1;
+   const int g = G > 1 ? lane / m : 0, ai = G > 1 ? lane - g * m : lane;
+   const int i = 64 * wave + ai;                              // the atom of this lane
+   const bool active = ai < m && g < G;
    const size_t iSlot = (size_t)iBox * a.cap + (active ? i : 0);
    const real_t xi = a.rx[iSlot], yi = a.ry[iSlot], zi = a.rz[iSlot];
    real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0);
-   for (int g = 0; g < NL_GROUPS; ++g) {
-      if (g) __syncthreads();                         // everyone is done reading the previous group
-      {  // all cells' loads in flight together, then the LDS stores (one global round trip per group)
+   for (int grp = 0; grp < NL_GROUPS; ++grp) {
+      if (grp) __syncthreads();                       // everyone is done reading the previous group
+      {  // all cells' loads in flight together, then the LDS stores (one global round trip per group); thread t stages slot t of every cell
          real_t vx[NL_GROUP_CELLS], vy[NL_GROUP_CELLS], vz[NL_GROUP_CELLS];
          int dst[NL_GROUP_CELLS];
          int off = 0;
 #pragma unroll
          for (int kk = 0; kk < NL_GROUP_CELLS; ++kk) {
-            const int jBox = a.nbr[(size_t)iBox * 27 + groupCell(g, kk)];
+            const int jBox = a.nbr[(size_t)iBox * 27 + groupCell(grp, kk)];
             const int nj = a.nAtoms[jBox];
-            const size_t js = (size_t)jBox * a.cap + (i < nj ? i : 0);      // unconditional loads (slot 0 always exists) so they all issue at once
+            const size_t js = (size_t)jBox * a.cap + (tid < nj ? tid : 0);      // unconditional loads (slot 0 always exists) so they all issue at once
             vx[kk] = a.rx[js]; vy[kk] = a.ry[js]; vz[kk] = a.rz[js];
-            dst[kk] = i < nj ? off + i : -1;
+            dst[kk] = tid < nj ? off + tid : -1;
             off += nj;
          }
 #pragma unroll
@@ -323,15 +330,17 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
       }
       __syncthreads();
       if (active) {
-         const int n = nl.count[(size_t)(iBox * NL_GROUPS + g) * a.cap + i];
-         const unsigned short* __restrict__ row = nl.list + ((size_t)(iBox * NL_GROUPS + g) * nl.rows) * a.cap + i;
+         const int nAll = nl.count[(size_t)(iBox * NL_GROUPS + grp) * a.cap + i];
+         const int n = nAll > g ? (nAll - g + G - 1) / G : 0;               // rows of this replica: g, g + G, ...
+         const unsigned short* __restrict__ row = nl.list + ((size_t)(iBox * NL_GROUPS + grp) * nl.rows + g) * a.cap + i;
+         const size_t step = (size_t)G * a.cap;
          // NL_BATCH rows per trip, the next trip's rows already in flight (the list streams from HBM), all LDS gathers of a trip
          // issued before the arithmetic: one LDS round trip per batch, not per pair
          int k = 0;
          int jn[NL_BATCH];
          if (n >= NL_BATCH) {
 #pragma unroll
-            for (int u = 0; u < NL_BATCH; ++u) jn[u] = row[(size_t)u * a.cap];
+            for (int u = 0; u < NL_BATCH; ++u) jn[u] = row[(size_t)u * step];
          }
          for (; k + NL_BATCH <= n; k += NL_BATCH) {
             int j[NL_BATCH];
@@ -339,7 +348,7 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
             for (int u = 0; u < NL_BATCH; ++u) j[u] = jn[u];
             if (k + 2 * NL_BATCH <= n) {
 #pragma unroll
-               for (int u = 0; u < NL_BATCH; ++u) jn[u] = row[(size_t)(k + NL_BATCH + u) * a.cap];
+               for (int u = 0; u < NL_BATCH; ++u) jn[u] = row[(size_t)(k + NL_BATCH + u) * step];
             }
             real_t dx[NL_BATCH], dy[NL_BATCH], dz[NL_BATCH];
 #pragma unroll
@@ -351,14 +360,24 @@ void LJ_Force_nl_slabs(LjArgs a, NlSlabView nl, int groupAtoms)
             }
          }
          for (; k < n; ++k) {
-            const int j = row[(size_t)k * a.cap];
+            const int j = row[(size_t)k * step];
             const real_t dx = xi - sp[j], dy = yi - sp[j + 1], dz = zi - sp[j + 2];
             const real_t r2 = dx*dx + dy*dy + dz*dz;
             if (r2 <= a.rc2) ljPair<ENERGY>(dx, dy, dz, r2, a, fx, fy, fz, e);
          }
       }
    }
-   if (active) {
+   if (G > 1) {                                               // (wave-uniform) all lanes take part; lanes < m keep the sum of the replicas
+      if (!active) { fx = fy = fz = e = R(0.0); }
+      real_t tx = fx, ty = fy, tz = fz, te = e;
+      for (int r = 1; r < G; ++r) {
+         const int src = (ai + r * m) & 63;
+         tx += bpermuteR(fx, src); ty += bpermuteR(fy, src); tz += bpermuteR(fz, src);
+         if (ENERGY) te += bpermuteR(e, src);
+      }
+      fx = tx; fy = ty; fz = tz; e = te;
+   }
+   if (active && g == 0) {
       const real_t fs = LJ_FORCE_SCALE(a);
       a.fx[iSlot] = fx * fs; a.fy[iSlot] = fy * fs; a.fz[iSlot] = fz * fs;
       if (ENERGY) a.e[iSlot] = e * R(2.0) * a.eps;
