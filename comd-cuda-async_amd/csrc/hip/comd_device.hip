@@ -390,7 +390,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
-                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1], sim->lj_pot.packedF[0], sim->lj_pot.packedF[1] };
+                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->eam_pot.brickGroup, sim->eam_pot.brickList, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1], sim->lj_pot.packedF[0], sim->lj_pot.packedF[1] };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->statusEvent) (void)hipEventDestroy((hipEvent_t)sim->statusEvent);
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
@@ -671,6 +671,7 @@ static EamArgs makeEamArgs(SimGpu* sim, int num_cells, int* cells_list)
    a.rc2 = sim->eam_pot.cutoff * sim->eam_pot.cutoff;
    a.phi = sim->eam_pot.phi; a.rho = sim->eam_pot.rho; a.f = sim->eam_pot.f;
    a.phiS = sim->eam_pot.phiS; a.rhoS = sim->eam_pot.rhoS;
+   a.sel = nullptr; a.tag = 0;
    return a;
 }
 
@@ -698,6 +699,23 @@ static void launchEamThreadAtom(SimGpu* sim, const EamArgs& a, int num_cells, hi
 
 // cta_cell, brick form (eam_brick_kernels.h): a workgroup stages the cells around a brick of 1 x BY x BZ cells once and its waves take the
 // brick's cells one at a time.  COMD_EAM_BRICK="by,bz" overrides the brick (experiments), COMD_EAM_BRICK_WAVES the waves per workgroup.
+static bool eamBrickPath(const SimGpu* sim, int method)
+{
+   return method == CTA_CELL && !(getenv("COMD_EAM_CTA") && !strcmp(getenv("COMD_EAM_CTA"), "cell"))
+          && (double)sim->boxes.nTotalBoxes * sim->maxAtoms * sizeof(real_t) < 4294967296.0;      // (the brick kernel stages with 32-bit byte offsets)
+}
+
+// The overlap mode's two lists as brick groups (eam_brick_kernels.h ClassifyBrickCells): 1 = this is the launch over SimGpu.boundary_cells, 2 = over
+// SimGpu.interior_cells, 0 = any other list (cell marks).  COMD_EAM_GROUPS=0 keeps the lists as they are given (A/B runs, tests).
+static int eamBrickGroupOf(const SimGpu* sim, const int* cells_list, int num_cells, int method)
+{
+   if (!cells_list || !eamBrickPath(sim, method)) return 0;
+   if (getenv("COMD_EAM_GROUPS") && atoi(getenv("COMD_EAM_GROUPS")) == 0) return 0;
+   if (cells_list == sim->boundary_cells && num_cells == sim->n_boundary_cells) return 1;
+   if (cells_list == sim->interior_cells && num_cells == sim->n_interior_cells) return 2;
+   return 0;
+}
+
 template <int STEP>
 static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* cells_list, hipStream_t st, int spline)
 {
@@ -767,7 +785,37 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    b.rows = sim->eam_pot.pairRowLen; b.rowsG = sim->eam_pot.pairRows; b.rowCountG = sim->eam_pot.pairRowCount;
    b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
    { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
-   if (cells_list) {      // a launch over a cell list (-a 1): mark the cells, every brick looks at its own
+   const int group = eamBrickGroupOf(sim, cells_list, num_cells, CTA_CELL);
+   if (group) {            // the boundary / interior launch of the overlap mode: whole bricks (a brick with cells of both lists would be staged twice per pass)
+      if (!sim->eam_pot.brickGroup || sim->eam_pot.brickGroupBy != b.by || sim->eam_pot.brickGroupBz != b.bz) {
+         if (!sim->eam_pot.brickGroup) sim->eam_pot.brickGroup = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
+         if (!sim->eam_pot.cellSel) {
+            sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
+            HIP_CHECK(hipMemsetAsync(sim->eam_pot.cellSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(int), st));
+         }
+         const int tag = ++sim->eam_pot.selTag;
+         const EamBrickArgs g = b;
+         if (sim->n_boundary_cells > 0)
+            hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(sim->n_boundary_cells, 256)), dim3(256), 0, st, sim->boundary_cells, sim->n_boundary_cells, sim->eam_pot.cellSel, tag);
+         const int nBricks = b.geom.g[0] * b.nby * b.nbz;
+         if (sim->eam_pot.brickList) HIP_CHECK(hipFree(sim->eam_pot.brickList));
+         sim->eam_pot.brickList = dalloc<int>((size_t)2 * nBricks, false);
+         hipLaunchKernelGGL(ClassifyBrickCells, dim3(ceilDiv(nBricks, 256)), dim3(256), 0, st, g, sim->eam_pot.cellSel, tag, sim->eam_pot.brickGroup, sim->eam_pot.brickList);
+         // the bricks of either group as a list (built once; the other stream of the overlap mode reads groups and lists too, so wait here):
+         // [0, n1) the bricks that hold a boundary cell, [nBricks, nBricks + n2) the others, each in brick order
+         std::vector<int> cls((size_t)nBricks), lists((size_t)2 * nBricks, 0);
+         HIP_CHECK(hipMemcpyAsync(cls.data(), sim->eam_pot.brickList, (size_t)nBricks * sizeof(int), hipMemcpyDeviceToHost, st));
+         HIP_CHECK(hipStreamSynchronize(st));
+         int n1 = 0, n2 = 0;
+         for (int i = 0; i < nBricks; ++i) { if (cls[i] == 1) lists[n1++] = i; else lists[(size_t)nBricks + n2++] = i; }
+         HIP_CHECK(hipMemcpyAsync(sim->eam_pot.brickList, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice, st));
+         HIP_CHECK(hipStreamSynchronize(st));
+         sim->eam_pot.brickCount[0] = n1; sim->eam_pot.brickCount[1] = n2; sim->eam_pot.brickListStride = nBricks;
+         sim->eam_pot.brickGroupBy = b.by; sim->eam_pot.brickGroupBz = b.bz;
+      }
+      // every cell of a listed brick is selected: no marks to look at (the embedding pass, a kernel over cells, uses brickGroup)
+      b.brickList = sim->eam_pot.brickList + (group == 1 ? 0 : sim->eam_pot.brickListStride);
+   } else if (cells_list) {      // a launch over any other cell list: mark the cells, every brick looks at its own
       if (!sim->eam_pot.cellSel) {
          // zeroed ON THE LAUNCH STREAM: hipMemset returns before the device has finished, and the -a 1 streams are non-blocking -- a zeroing on
          // the null stream can land after the marks of the first launch (seen once in four-rank runs: a first force evaluation that skipped cells)
@@ -782,7 +830,8 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    { const char* e = getenv("COMD_EAM_BRICK_WAVES"); if (e && atoi(e) >= 4 && atoi(e) <= 16) waves = atoi(e); }
    const size_t lds = eamBrickLdsBytes(STEP, tableDoubles, b.imageCap, b.rows, waves);
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
-   const int grid = b.geom.g[0] * b.nby * b.nbz;
+   const int grid = group ? sim->eam_pot.brickCount[group - 1] : b.geom.g[0] * b.nby * b.nbz;
+   if (grid <= 0) return;
 #define COMD_LAUNCH_EAM_BRICK(TAB, SPL) do { \
       static size_t attrSet = 0; \
       if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_brick<STEP, TAB, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; } \
@@ -831,8 +880,7 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (spline)                       hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false, true>), dim3(nBlocks), dim3(256), 0, st, a, nl);
       else if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true, false>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
       else                              hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
-   } else if (method == CTA_CELL && !(getenv("COMD_EAM_CTA") && !strcmp(getenv("COMD_EAM_CTA"), "cell"))
-              && (double)sim->boxes.nTotalBoxes * sim->maxAtoms * sizeof(real_t) < 4294967296.0) {      // (the brick kernel stages with 32-bit byte offsets)
+   } else if (eamBrickPath(sim, method)) {
       launchEamBrick<STEP>(sim, a, num_cells, cells_list, st, spline);
    } else if (method == CTA_CELL) {
       // COMD_EAM_CTA=cell: round 2's form, a wave stages the stencil of every cell for itself (nl_kernels.h EAM_Force_cta_cell); kept for A/B runs
@@ -906,6 +954,9 @@ extern "C" void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, i
    if (num_cells <= 0) return;
    if (sim->fuseEmbed && method == CTA_CELL) return;      /* eamForce1Gpu[Async] has done it for these cells (SimGpu.fuseEmbed) */
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
+   // cta_cell in the overlap mode: pass 1 took whole bricks (launchEamBrick), the embedding follows the same groups over all local cells
+   const int group = sim->eam_pot.brickGroup ? eamBrickGroupOf(sim, cells_list, num_cells, method) : 0;
+   if (group) { a.cells = nullptr; a.nCells = num_cells = sim->boxes.nLocalBoxes; a.sel = sim->eam_pot.brickGroup; a.tag = group; }
    ForceTimer timer(sim, S(stream));
    hipLaunchKernelGGL(EAM_Force_embed, dim3(ceilDiv((long)num_cells * sim->maxAtoms, 256)), dim3(256), 0, S(stream), a);
    LAUNCH_CHECK();

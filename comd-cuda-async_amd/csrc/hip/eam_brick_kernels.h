@@ -32,6 +32,7 @@ struct EamBrickArgs {
    unsigned* rowsG;                       // [local slots][EAM_ROW_WORDS] words of two image numbers, laid out [lane of the atom][trip], pass 1 -> pass 3
    unsigned short* rowCountG;             // [local slots]
    const int* sel; int tag;               // cell selection: NULL = every local cell, else the cells with sel[c] == tag
+   const int* brickList;                  // NULL: workgroup w takes brick w; else brick brickList[w] (the bricks of one group of the overlap mode, every cell selected)
    int fuseEmbed;
    int* status;
    int debug;                             // experiments (COMD_EAM_ABLATE): 1 no build sweeps, 2 no pair evaluation
@@ -58,6 +59,26 @@ void MarkCells(const int* __restrict__ list, int n, int* __restrict__ sel, int t
 {
    const int i = blockIdx.x * blockDim.x + threadIdx.x;
    if (i < n) sel[list[i]] = tag;
+}
+
+// Brick groups for the overlap mode (-a 1).  The host splits the local cells into boundary cells (two rings) and interior cells and launches every
+// pass once per list; a brick that holds cells of both lists would be staged twice per pass, for a few cells each time.  The groups make the split at
+// brick granularity: group[c] = 1 for every cell of a brick that holds a boundary cell (marks[c] == tag), 2 for the cells of the other bricks.
+__global__ __launch_bounds__(256)
+void ClassifyBrickCells(EamBrickArgs b, const int* __restrict__ marks, int tag, int* __restrict__ group, int* __restrict__ brickClass)
+{
+   const int bid = blockIdx.x * blockDim.x + threadIdx.x;
+   const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2];
+   if (bid >= gx * b.nby * b.nbz) return;
+   const int bx = bid % gx, by0 = ((bid / gx) % b.nby) * b.by, bz0 = (bid / (gx * b.nby)) * b.bz;
+   bool any = false;
+   for (int dz = 0; dz < b.bz; ++dz)
+      for (int dy = 0; dy < b.by; ++dy)
+         if (by0 + dy < gy && bz0 + dz < gz) any = any || marks[comdBoxFromTuple(&b.geom, bx, by0 + dy, bz0 + dz)] == tag;
+   for (int dz = 0; dz < b.bz; ++dz)
+      for (int dy = 0; dy < b.by; ++dy)
+         if (by0 + dy < gy && bz0 + dz < gz) group[comdBoxFromTuple(&b.geom, bx, by0 + dy, bz0 + dz)] = any ? 1 : 2;
+   brickClass[bid] = any ? 1 : 2;
 }
 
 template <int STEP, bool LDS_TABLES, bool SPLINE>
@@ -87,7 +108,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
 
    // ---- the brick and its selected cells -------------------------------------------------------------------------------------------
    const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2];
-   const int bid = xcdRemap(blockIdx.x, gridDim.x);          // x fastest: consecutive bricks share two thirds of their block
+   const int bid = b.brickList ? b.brickList[xcdRemap(blockIdx.x, gridDim.x)] : xcdRemap(blockIdx.x, gridDim.x);      // x fastest: consecutive bricks share two thirds of their block
    const int bx = bid % gx, by0 = ((bid / gx) % b.nby) * b.by, bz0 = (bid / (gx * b.nby)) * b.bz;
    const int HY = b.by + 2, HZ = b.bz + 2, NH = 3 * HY * HZ, NC = b.by * b.bz;
    unsigned long long selMask;

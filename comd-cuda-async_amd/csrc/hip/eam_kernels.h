@@ -25,6 +25,7 @@ struct EamArgs {
    real_t rc2;
    InterpolationObjectGpu phi, rho, f;
    InterpolationSplineObjectGpu phiS, rhoS;
+   const int* __restrict__ sel; int tag;      // EAM_Force_embed: when sel is given, only the cells with sel[cell] == tag (the brick groups of cta_cell, comd_device.hip)
 };
 
 // ---------------------------------------------------------------------------------------------------
@@ -116,6 +117,7 @@ void EAM_Force_embed(EamArgs a)
    if (ci >= a.nCells) return;
    const int iBox = a.cells ? a.cells[ci] : ci;
    if (ia >= a.nAtoms[iBox]) return;
+   if (a.sel && a.sel[iBox] != a.tag) return;
    const size_t iOff = (size_t)iBox * a.cap + ia;
    const TableView fT = makeTable(a.f, a.f.values);
    real_t F, dF;

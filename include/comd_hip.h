@@ -87,6 +87,11 @@ typedef struct EamPotentialGpu {
    /* cta_cell, brick form (round 3, hip/eam_brick_kernels.h): the selection marks of launches that cover a cell list (the cells with
     * cellSel[c] == the launch's tag); allocated on first use.  The rows above keep their layout, the numbers now index the LDS image of the atom's brick. */
    int     brickImageCap;              /* host: records the LDS image of a brick holds, fixed by the first brick launch from the occupancies it finds */
+   int*    brickGroup;                 /* device [nLocalBoxes]: 1 = the cell's brick holds a boundary cell, 2 = it does not: the overlap mode's boundary / interior launches of cta_cell
+                                        * take whole bricks (a brick with cells of both lists would be staged twice per pass); built by the first launch over boundary_cells or interior_cells */
+   int     brickGroupBy, brickGroupBz; /* the brick shape the groups were built for */
+   int*    brickList;                  /* device [2][brickListStride]: the bricks of group 1, of group 2 (what a group launch's workgroups take) */
+   int     brickCount[2], brickListStride;
    int*    cellSel;                    /* device [nLocalBoxes] */
    int     selTag;                     /* host: tag of the last list launch */
 } EamPotentialGpu;

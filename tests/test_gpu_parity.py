@@ -146,6 +146,25 @@ def test_lj_wave_candidate_lists_and_their_fallbacks(gpu, orc, monkeypatch, env)
         assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
 
 
+@pytest.mark.parametrize("env", [{}, {"COMD_EAM_GROUPS": "0"}, {"COMD_EAM_BRICK": "2,3"}])
+def test_eam_overlap_mode_takes_whole_bricks(gpu, orc, monkeypatch, env):
+    """-a 1 launches every EAM pass once over the boundary cells and once over the interior cells.  cta_cell makes that split at brick
+    granularity (every cell of a brick that holds a boundary cell goes with the boundary launch: no brick is staged twice per pass;
+    comd_device.hip eamBrickGroupOf).  Forces, energies, densities and dF/drho after three steps must be the oracle's -- with the groups,
+    with the lists taken cell by cell (COMD_EAM_GROUPS=0), and with a brick shape that does not divide the grid."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with gpu.Simulation(_args((14, 12, 13), 1, 0.2, "cta_cell", extra=("-a", 1))) as sim:
+        o = orc.Oracle((14, 12, 13), eam=1, delta=0.2, cap=max(sim.max_atoms, 64))
+        sim.step(3)
+        o.step(3)
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * np.abs(fo).max()
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < TOL["eam_density_abs"]
+        assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < TOL["eam_dfembed_abs"]
+
+
 def test_lj_wave_candidate_lists_do_not_lose_a_pair(gpu, monkeypatch):
     """The list build prunes in single precision on positions relative to the corner of the local domain, with a margin for that rounding
     (comd_device.hip ljBoxMarginsF); the force kernel decides every pair on the fp64 records.  With the lists and with the plain 27-cell
