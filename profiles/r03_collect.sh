@@ -36,6 +36,8 @@ COMD_LOOPBACK_TRANSPORT=1 python bench.py --no-variants --no-cpu-baseline > $O/l
 COMD_LOOPBACK_TRANSPORT=1 COMD_HALO_HANDSHAKE=1 python bench.py --no-variants --no-cpu-baseline > $O/loopback_lj_handshake.json 2>/dev/null
 COMD_LOOPBACK_TRANSPORT=1 python bench.py --pot eam --no-variants --no-cpu-baseline > $O/loopback_eam.json 2>/dev/null
 COMD_LOOPBACK_TRANSPORT=1 COMD_HALO_HANDSHAKE=1 python bench.py --pot eam --no-variants --no-cpu-baseline > $O/loopback_eam_handshake.json 2>/dev/null
+COMD_LOOPBACK_TRANSPORT=1 python bench.py --async-halo 1 --no-variants --no-cpu-baseline --no-target-line > $O/loopback_lj_overlap.json 2>/dev/null
+COMD_LOOPBACK_TRANSPORT=1 python bench.py --pot eam --async-halo 1 --no-variants --no-cpu-baseline > $O/loopback_eam_overlap.json 2>/dev/null
 python bench.py --no-variants --no-cpu-baseline --no-target-line > $O/plain_lj.json 2>/dev/null
 python bench.py --pot eam --no-variants --no-cpu-baseline > $O/plain_eam.json 2>/dev/null
 COMD_EAM_CTA=cell python bench.py --pot eam --no-variants --no-cpu-baseline > $O/plain_eam_round2_kernel.json 2>/dev/null

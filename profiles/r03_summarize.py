@@ -42,12 +42,13 @@ def main():
     if g2:
         shutil.copy(g2[0], os.path.join(P, "r03_80_eam_cta_cell_round2_kernel_kernel_stats.csv"))
     loop = {}
-    for tag in ("plain_lj", "loopback_lj", "loopback_lj_handshake", "plain_eam", "loopback_eam", "loopback_eam_handshake"):
+    for tag in ("plain_lj", "loopback_lj", "loopback_lj_handshake", "loopback_lj_overlap", "plain_eam", "loopback_eam", "loopback_eam_handshake", "loopback_eam_overlap"):
         d = json.load(open(os.path.join(F, tag + ".json")))
         loop[tag] = {"ms_per_step": d["ms_per_step"], "force_ms_per_step": d["roofline"]["kernel_ms_per_step"], "value": d["value"], "config": d["config"]}
     loop["_about"] = ("One GPU, 80^3.  plain: no transport (a rank that is its own neighbour unpacks straight from its send buffers).  loopback: COMD_LOOPBACK_TRANSPORT=1, every halo "
                       "message and reduction goes through a one-rank RCCL communicator (ncclSend/ncclRecv to itself) with the sized protocol (no handshake, no host sync); "
-                      "loopback_*_handshake: COMD_HALO_HANDSHAKE=1, the exact-size handshake of round 1 (three host syncs per exchange).")
+                      "loopback_*_handshake: COMD_HALO_HANDSHAKE=1, the exact-size handshake of round 1 (three host syncs per exchange); loopback_*_overlap: the sized protocol with -a 1 "
+                      "(interior cells on a second stream during the exchange: the mode bench.py runs for N > 1).")
     json.dump(loop, open(os.path.join(P, "r03_rccl_loopback_bench.json"), "w"), indent=1)
 
     pmc = json.load(open(os.path.join(F, "pmc_summary.json")))
@@ -109,7 +110,9 @@ def main():
     lp = loop
     out.append("RCCL on one GPU (`profiles/r03_rccl_loopback_bench.json`): ms/step plain / loopback with the sized protocol / loopback with round 1's handshake: "
                f"LJ {lp['plain_lj']['ms_per_step']:.3f} / {lp['loopback_lj']['ms_per_step']:.3f} / {lp['loopback_lj_handshake']['ms_per_step']:.3f}; "
-               f"EAM {lp['plain_eam']['ms_per_step']:.3f} / {lp['loopback_eam']['ms_per_step']:.3f} / {lp['loopback_eam_handshake']['ms_per_step']:.3f}.\n")
+               f"EAM {lp['plain_eam']['ms_per_step']:.3f} / {lp['loopback_eam']['ms_per_step']:.3f} / {lp['loopback_eam_handshake']['ms_per_step']:.3f}."
+               + (f"  With the overlap mode (`-a 1`: what `bench.py --gpus N` runs for N > 1) through the loopback: LJ {lp['loopback_lj_overlap']['ms_per_step']:.3f}, EAM {lp['loopback_eam_overlap']['ms_per_step']:.3f}."
+                  if "loopback_lj_overlap" in lp and "loopback_eam_overlap" in lp else "") + "\n")
     tl = d.get("target_line")
     if tl and "value" in tl:
         out.append(f"LJ 256^3 (the BASELINE target line; `target_line` of the same bench run): {tl['ms_per_step']:.1f} ms/step = {tl['value'] / 1e6:.0f} M atom-updates/s, force kernel "
