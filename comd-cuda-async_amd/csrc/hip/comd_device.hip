@@ -8,6 +8,8 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
+#include <map>
+#include <utility>
 
 #include "comd_hip.h"
 #include "device_common.h"
@@ -34,6 +36,16 @@ static int g_rank = 0;
 
 static inline hipStream_t S(comdStream_t s) { return (hipStream_t)s; }
 static inline int ceilDiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of (device, kernel): remember the largest size asked for per pair
+static void allowDynamicLds(const void* fn, size_t lds)
+{
+   static std::map<std::pair<int, const void*>, size_t> granted;
+   int dev = 0; HIP_CHECK(hipGetDevice(&dev));
+   size_t& g = granted[std::make_pair(dev, fn)];
+   if (lds > g) { HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); g = lds; }
+}
+
 
 // ---- force-kernel timing (bench.py roofline leg): per simulation, SimGpu.timing -----------------------------------
 // Two classes of launches are timed apart: kind 0 the force kernels proper (the kernel the roofline object names), kind 1 what a force
@@ -275,6 +287,22 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
          nl->pairlistWaves = (threads + 63) / 64;
          nl->pairlist = dalloc<unsigned>((size_t)cfg->nLocalBoxes * nl->pairlistWaves * LJ_CTA_SLABS * LJ_PL_WORDS);
          nl->pairlistBuildId = -1;
+      } else if (cfg->do_eam && !getenv("COMD_NL_GLOBAL") && !(getenv("COMD_EAM_NL") && !strcmp(getenv("COMD_EAM_NL"), "lds"))
+                 && (double)cfg->nTotalBoxes * cfg->maxAtoms * sizeof(real_t) < 4294967296.0) {
+         // [round 4] EAM: rows of the brick kernel (eam_brick_kernels.h, LISTED): 16-bit record numbers in the LDS image of the atom's brick, kept from one
+         // list build to the next.  Any table size (setfl tables and -P coefficients are read through L2), any cell capacity.
+         nl->slabFormat = 4;
+         nl->brickRowLen = (nl->maxNeighbors + 7) / 8 * 8;
+         if (nl->brickRowLen > 2 * EAM_LIST_WORDS * 16) nl->brickRowLen = 2 * EAM_LIST_WORDS * 16;      // 16 lanes x 12 words x 2 numbers
+         const int lanesMin = (nl->brickRowLen + 2 * EAM_LIST_WORDS - 1) / (2 * EAM_LIST_WORDS);          // as the kernel derives them from `rows`
+         nl->brickRoundAtoms = 64 / lanesMin < 16 ? 64 / lanesMin : 16;
+         nl->brickRounds = (cfg->maxAtoms + nl->brickRoundAtoms - 1) / nl->brickRoundAtoms;
+         const int lanesPerAtom = 64 / nl->brickRoundAtoms;                                                // the fewest lanes an atom is ever dealt to
+         int words = (nl->brickRowLen / 2 + lanesPerAtom - 1) / lanesPerAtom;
+         if (words > EAM_LIST_WORDS) words = EAM_LIST_WORDS;
+         nl->brickQuads = (words + 3) / 4;
+         nl->brickRows = dalloc<unsigned>((size_t)cfg->nLocalBoxes * nl->brickRounds * nl->brickQuads * 64 * 4, false);
+         nl->brickRowCount = dalloc<unsigned short>(localSlots);
       } else if (cfg->do_eam && cfg->maxAtoms <= 64 && eamCtaTableBytes(1, cfg->nRho, cfg->nPhi) <= 32 * 1024 && !getenv("COMD_NL_GLOBAL")) {
          // EAM with LDS-sized tables: 16-bit entries into the wave's staging of the whole 27-cell stencil
          nl->slabFormat = 2;
@@ -390,7 +418,8 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
-                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->eam_pot.brickGroup, sim->eam_pot.brickList, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1], sim->lj_pot.packedF[0], sim->lj_pot.packedF[1] };
+                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->eam_pot.brickGroup, sim->eam_pot.brickList, sim->eam_pot.brickSel, sim->eam_pot.brickStats,
+                    sim->atoms.neighborList.brickRows, sim->atoms.neighborList.brickRowCount, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1], sim->lj_pot.packedF[0], sim->lj_pot.packedF[1] };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->statusEvent) (void)hipEventDestroy((hipEvent_t)sim->statusEvent);
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
@@ -418,6 +447,7 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
       if (st[2])     fprintf(stderr, "a halo message overflowed its buffer, or grew by more than 12.5 %% + 64 atoms in one step (COMD_HALO_HANDSHAKE=1 exchanges exact sizes); ");
       if (st[3] & 1) fprintf(stderr, "an atom has more neighbours inside the cutoff than a row of the EAM cta_cell kernel holds (1.5 x the FCC count; use -m thread_atom); ");
       if (st[3] & 2) fprintf(stderr, "an atom has more than %d neighbours inside cutoff + skin (raise --maxNeighbors); ", sim->atoms.neighborList.maxNeighbors);
+      if (st[3] & 4) fprintf(stderr, "eamForce3Gpu[Async] covered the cells with another partition than eamForce1Gpu[Async] (include/comd_hip.h: same lists in both passes); ");
       fprintf(stderr, "\n");
       exit(-1);
    }
@@ -600,12 +630,8 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       NlSlabView v; v.list = n->list16; v.count = n->nNeighbors; v.rows = n->slabRows;
       const int threads = ((n->maxCellAtoms + 63) / 64) * 64;
       const size_t lds = (size_t)3 * n->maxSlabAtoms * sizeof(real_t);
-      static size_t attrSet = 0;
-      if (lds > attrSet) {
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_nl_slabs<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_nl_slabs<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         attrSet = lds;
-      }
+      allowDynamicLds((const void*)LJ_Force_nl_slabs<true>, lds);
+      allowDynamicLds((const void*)LJ_Force_nl_slabs<false>, lds);
       if (sim->needEnergy) hipLaunchKernelGGL(LJ_Force_nl_slabs<true>, dim3(num_cells), dim3(threads), lds, S(stream), a, v, n->maxSlabAtoms);
       else              hipLaunchKernelGGL(LJ_Force_nl_slabs<false>, dim3(num_cells), dim3(threads), lds, S(stream), a, v, n->maxSlabAtoms);
    } else if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
@@ -615,16 +641,9 @@ extern "C" void ljForceGpuAsync(SimGpu* sim, int num_cells, int* cells_list, int
       else              hipLaunchKernelGGL(LJ_Force_thread_atom_nl<false>, dim3(nBlocks), dim3(256), 0, S(stream), a, nl);
    } else if (method == CTA_CELL) {
       const size_t lds = ljCtaLdsBytes(sim->maxAtoms);
-      static size_t attrSet = 0;
-      if (lds > attrSet) {
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         HIP_CHECK(hipFuncSetAttribute((const void*)LJ_Force_cta_cell<2, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-         attrSet = lds;
-      }
+      allowDynamicLds((const void*)LJ_Force_cta_cell<0, true>, lds); allowDynamicLds((const void*)LJ_Force_cta_cell<0, false>, lds);
+      allowDynamicLds((const void*)LJ_Force_cta_cell<1, true>, lds); allowDynamicLds((const void*)LJ_Force_cta_cell<1, false>, lds);
+      allowDynamicLds((const void*)LJ_Force_cta_cell<2, true>, lds); allowDynamicLds((const void*)LJ_Force_cta_cell<2, false>, lds);
       // threads = atoms of the fullest cell the host has seen (+16), rounded to whole waves, at most 256; each thread can own two atoms
       int threads = sim->maxAtoms < 256 ? sim->maxAtoms : 256;
       // (not with pairlists: their bits are per wave, so the thread -> atom map must not change between the generating call and the users)
@@ -698,9 +717,15 @@ static void launchEamThreadAtom(SimGpu* sim, const EamArgs& a, int num_cells, hi
 }
 
 // cta_cell, brick form (eam_brick_kernels.h): a workgroup stages the cells around a brick of 1 x BY x BZ cells once and its waves take the
-// brick's cells one at a time.  COMD_EAM_BRICK="by,bz" overrides the brick (experiments), COMD_EAM_BRICK_WAVES the waves per workgroup.
+// brick's cells one at a time.  COMD_EAM_BRICK="by,bz" overrides the brick (experiments).  The Verlet-list method of EAM (slabFormat 4) runs on the
+// same kernel with LISTED = true: rows built once per list build, both passes read them back.
+static bool eamListedBrick(const SimGpu* sim, int method)
+{
+   return (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat == 4;
+}
 static bool eamBrickPath(const SimGpu* sim, int method)
 {
+   if (eamListedBrick(sim, method)) return true;
    return method == CTA_CELL && !(getenv("COMD_EAM_CTA") && !strcmp(getenv("COMD_EAM_CTA"), "cell"))
           && (double)sim->boxes.nTotalBoxes * sim->maxAtoms * sizeof(real_t) < 4294967296.0;      // (the brick kernel stages with 32-bit byte offsets)
 }
@@ -716,76 +741,113 @@ static int eamBrickGroupOf(const SimGpu* sim, const int* cells_list, int num_cel
    return 0;
 }
 
-template <int STEP>
-static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* cells_list, hipStream_t st, int spline)
+// The brick shape of a simulation: 1 x 4 x 2 cells unless COMD_EAM_BRICK says otherwise; fixed by the first launch (rows index the image of that shape).
+static void eamBrickShape(SimGpu* sim, bool listed, int* by, int* bz)
 {
-   const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
-   const bool tablesInLds = !spline && tableBytes <= 32 * 1024;      // funcfl tables (500 samples) live in the LDS; setfl (10000) and spline coefficients stay in L2
+   if (!sim->eam_pot.brickBy) {
+      int y = 4, z = 2;
+      const int maxCells = listed ? (EAM_BRICK_STAGE_LISTED * 256) / 32 : EAM_BRICK_MAX_CELLS;      // what the staging loop covers (eam_brick_kernels.h)
+      const char* e = getenv("COMD_EAM_BRICK"); int ey = 0, ez = 0;
+      if (e && sscanf(e, "%d,%d", &ey, &ez) == 2 && ey >= 1 && ez >= 1 && 3 * (ey + 2) * (ez + 2) <= maxCells && ey * ez <= 64) { y = ey; z = ez; }
+      sim->eam_pot.brickBy = y; sim->eam_pot.brickBz = z;
+   }
+   *by = sim->eam_pot.brickBy; *bz = sim->eam_pot.brickBz;
+}
+
+static void eamBrickGeometry(SimGpu* sim, bool listed, EamBrickArgs* b)
+{
+   memset(b, 0, sizeof *b);
+   for (int k = 0; k < 3; ++k) { b->geom.g[k] = sim->boxes.gridSize[k]; b->geom.lmin[k] = sim->boxes.localMin[k]; b->geom.lmax[k] = sim->boxes.localMax[k]; b->geom.inv[k] = sim->boxes.invBoxSize[k]; }
+   b->geom.nLocal = sim->boxes.nLocalBoxes; b->geom.nTotal = sim->boxes.nTotalBoxes;
+   b->geom.lookup = sim->boxes.boxIDLookUp; b->geom.reverse = sim->boxes.boxIDLookUpReverse;
+   eamBrickShape(sim, listed, &b->by, &b->bz);
+   b->nby = ceilDiv(b->geom.g[1], b->by); b->nbz = ceilDiv(b->geom.g[2], b->bz);
+}
+
+// The image must hold the atoms of the fullest BLOCK (3 x (by + 2) x (bz + 2) cells), not the mean: the lattice and the cell grid are incommensurate,
+// and at 80^3 the blocks of a 1 x 4 x 2 brick hold 755 atoms on average and up to 918.  A brick whose block outgrows the image takes the
+// thread-per-atom form (correct, many times slower), so the occupancies are read once, the fullest block of this brick shape is found and the image
+// sized for it + 1 % + 8 (blocks gain or lose a handful of atoms through their surface as the lattice moves).  Both passes use that size.
+// Called by the first launch; by every Verlet-list build (the cells were just re-binned); and again when comdEamBrickStats finds bricks in the fall-back.
+static void eamBrickSizeImage(SimGpu* sim, const EamBrickArgs& b, hipStream_t st, bool listed)
+{
+   const double cellVol = 1.0 / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);
+   const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
+   std::vector<int> counts((size_t)sim->boxes.nTotalBoxes), lookup;
+   HIP_CHECK(hipMemcpyAsync(counts.data(), sim->boxes.nAtoms, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+   if (sim->boxes.boxIDLookUp) {
+      lookup.resize((size_t)sim->boxes.nLocalBoxes);
+      HIP_CHECK(hipMemcpyAsync(lookup.data(), sim->boxes.boxIDLookUp, lookup.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+   }
+   HIP_CHECK(hipStreamSynchronize(st));
+   CellGeom hg = b.geom; hg.lookup = lookup.empty() ? nullptr : lookup.data(); hg.reverse = nullptr;
+   const int gx = hg.g[0], gy = hg.g[1], gz = hg.g[2];
+   // per (y, z) row of three x cells, then the (by + 2) x (bz + 2) window of rows around every brick
+   long fullest = 0;
+   std::vector<int> row3((size_t)gx * (gy + 2) * (gz + 2));
+   for (int z = -1; z <= gz; ++z) for (int y = -1; y <= gy; ++y) for (int x = 0; x < gx; ++x)
+      row3[(size_t)x + (size_t)gx * ((y + 1) + (size_t)(gy + 2) * (z + 1))] =
+         counts[comdBoxFromTuple(&hg, x - 1, y, z)] + counts[comdBoxFromTuple(&hg, x, y, z)] + counts[comdBoxFromTuple(&hg, x + 1, y, z)];
+   // (only blocks made of local cells count: with -a 1 the first launch runs while the halo cells are still being filled; the lattice is periodic, the
+   // blocks at the faces are no fuller than those inside.  A grid too small to have such blocks takes the mean density + 25 %.)
+   for (int bzI = 0; bzI < b.nbz; ++bzI) for (int byI = 0; byI < b.nby; ++byI) for (int x = 1; x < gx - 1; ++x) {
+      if (byI * b.by - 1 < 0 || byI * b.by + b.by > gy - 1 || bzI * b.bz - 1 < 0 || bzI * b.bz + b.bz > gz - 1) continue;
+      long sum = 0;
+      for (int z = bzI * b.bz - 1; z <= bzI * b.bz + b.bz; ++z)
+         for (int y = byI * b.by - 1; y <= byI * b.by + b.by; ++y) sum += row3[(size_t)x + (size_t)gx * ((y + 1) + (size_t)(gy + 2) * (z + 1))];
+      if (sum > fullest) fullest = sum;
+   }
+   if (fullest == 0) fullest = (long)(1.25 * 3 * (b.by + 2) * (b.bz + 2) * cellVol * 4.0 / (lat * lat * lat));
+   int cap = (((int)(fullest * 1.01) + 8 + (listed ? 1 : 0) + 7) / 8) * 8;      // (listed launches keep one more record: the far-away one that pads odd rows)
+   if (cap < 256) cap = 256;
+   if (cap > 4096) cap = 4096;                            // 16-bit numbers would reach 65535; beyond 4096 records the cells take the thread-per-atom form
+   { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) cap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force the fallback
+   sim->eam_pot.brickImageCap = cap;
+}
+
+template <int STEP>
+static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* cells_list, hipStream_t st, int spline, bool listed, int method)
+{
+   const size_t tableBytes = eamCtaTableBytes(STEP == 0 ? 1 : STEP, a.rho.n, a.phi.n);
+   const bool tablesInLds = STEP != 0 && !spline && tableBytes <= 32 * 1024;      // funcfl tables (500 samples) live in the LDS; setfl (10000) and spline coefficients stay in L2
    const bool sameGrid = a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
    size_t tableDoubles = 0;
    if (tablesInLds) tableDoubles = STEP == 1 ? (size_t)2 * (a.rho.n + 3) + (sameGrid ? 0 : (a.phi.n + 3 - (a.rho.n + 3))) : (size_t)(a.rho.n + 3);
-   EamBrickArgs b; memset(&b, 0, sizeof b);
-   for (int k = 0; k < 3; ++k) { b.geom.g[k] = sim->boxes.gridSize[k]; b.geom.lmin[k] = sim->boxes.localMin[k]; b.geom.lmax[k] = sim->boxes.localMax[k]; b.geom.inv[k] = sim->boxes.invBoxSize[k]; }
-   b.geom.nLocal = sim->boxes.nLocalBoxes; b.geom.nTotal = sim->boxes.nTotalBoxes;
-   b.geom.lookup = sim->boxes.boxIDLookUp; b.geom.reverse = sim->boxes.boxIDLookUpReverse;
-   b.by = 4; b.bz = 2;
-   { const char* e = getenv("COMD_EAM_BRICK"); int y = 0, z = 0; if (e && sscanf(e, "%d,%d", &y, &z) == 2 && y >= 1 && z >= 1 && 3 * (y + 2) * (z + 2) <= EAM_BRICK_MAX_CELLS && y * z <= 64) { b.by = y; b.bz = z; } }
-   b.nby = ceilDiv(b.geom.g[1], b.by); b.nbz = ceilDiv(b.geom.g[2], b.bz);
-   // The image must hold the atoms of the fullest BLOCK (3 x (by + 2) x (bz + 2) cells), not the mean: the lattice and the cell grid are incommensurate,
-   // and at 80^3 the blocks of a 1 x 4 x 2 brick hold 755 atoms on average and up to 918.  A brick whose block outgrows the image takes the
-   // thread-per-atom form (correct, many times slower), so the first launch reads the occupancies once, finds the fullest block of this brick shape and
-   // sizes the image for it + 1 % + 8 (blocks gain or lose a handful of atoms through their surface as the lattice moves).  Both passes use that size.
-   const double cellVol = 1.0 / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);
+   EamBrickArgs b;
+   eamBrickGeometry(sim, listed, &b);
    const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
-   if (!sim->eam_pot.brickImageCap) {
-      std::vector<int> counts((size_t)sim->boxes.nTotalBoxes), lookup;
-      HIP_CHECK(hipMemcpyAsync(counts.data(), sim->boxes.nAtoms, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));
-      if (sim->boxes.boxIDLookUp) {
-         lookup.resize((size_t)sim->boxes.nLocalBoxes);
-         HIP_CHECK(hipMemcpyAsync(lookup.data(), sim->boxes.boxIDLookUp, lookup.size() * sizeof(int), hipMemcpyDeviceToHost, st));
-      }
-      HIP_CHECK(hipStreamSynchronize(st));
-      CellGeom hg = b.geom; hg.lookup = lookup.empty() ? nullptr : lookup.data(); hg.reverse = nullptr;
-      const int gx = hg.g[0], gy = hg.g[1], gz = hg.g[2];
-      // per (y, z) row of three x cells, then the (by + 2) x (bz + 2) window of rows around every brick
-      long fullest = 0;
-      std::vector<int> row3((size_t)gx * (gy + 2) * (gz + 2));
-      for (int z = -1; z <= gz; ++z) for (int y = -1; y <= gy; ++y) for (int x = 0; x < gx; ++x)
-         row3[(size_t)x + (size_t)gx * ((y + 1) + (size_t)(gy + 2) * (z + 1))] =
-            counts[comdBoxFromTuple(&hg, x - 1, y, z)] + counts[comdBoxFromTuple(&hg, x, y, z)] + counts[comdBoxFromTuple(&hg, x + 1, y, z)];
-      // (only blocks made of local cells count: with -a 1 the first launch runs while the halo cells are still being filled; the lattice is periodic, the
-      // blocks at the faces are no fuller than those inside.  A grid too small to have such blocks takes the mean density + 25 %.)
-      for (int bzI = 0; bzI < b.nbz; ++bzI) for (int byI = 0; byI < b.nby; ++byI) for (int x = 1; x < gx - 1; ++x) {
-         if (byI * b.by - 1 < 0 || byI * b.by + b.by > gy - 1 || bzI * b.bz - 1 < 0 || bzI * b.bz + b.bz > gz - 1) continue;
-         long sum = 0;
-         for (int z = bzI * b.bz - 1; z <= bzI * b.bz + b.bz; ++z)
-            for (int y = byI * b.by - 1; y <= byI * b.by + b.by; ++y) sum += row3[(size_t)x + (size_t)gx * ((y + 1) + (size_t)(gy + 2) * (z + 1))];
-         if (sum > fullest) fullest = sum;
-      }
-      if (fullest == 0) fullest = (long)(1.25 * 3 * (b.by + 2) * (b.bz + 2) * cellVol * 4.0 / (lat * lat * lat));
-      int cap = (((int)(fullest * 1.01) + 8 + 7) / 8) * 8;
-      if (cap < 256) cap = 256;
-      if (cap > 4096) cap = 4096;                            // 16-bit numbers would reach 65535; beyond 4096 records the cells take the thread-per-atom form
-      { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) cap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force the fallback
-      sim->eam_pot.brickImageCap = cap;
-   }
+   if (!sim->eam_pot.brickImageCap) eamBrickSizeImage(sim, b, st, listed);
    b.imageCap = sim->eam_pot.brickImageCap;
-   // rows per atom: the cutoff sphere at that density + 50 %, a multiple of 8
-   const double rc = sim->eam_pot.cutoff;
-   int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
-   if (rows < 32) rows = 32;
-   if (rows > 256) rows = 256;
-   if (rows > 16 * 16) rows = 256;
-   if (!sim->eam_pot.pairRows) {                             // rows pass 1 leaves for pass 3: [slot][lane of the atom][trip] words
-      const size_t slotsLocal = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
-      sim->eam_pot.pairRows = dalloc<unsigned>(slotsLocal * EAM_ROW_WORDS, false);
-      sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal, false);      // (written by pass 1 before pass 3 reads it; no zeroing that could race with that)
-      sim->eam_pot.pairRowLen = rows;
+   if (!sim->eam_pot.brickStats) sim->eam_pot.brickStats = dalloc<int>(2);
+   b.stats = sim->eam_pot.brickStats;
+   if (listed) {
+      NeighborListGpu* n = &sim->atoms.neighborList;
+      b.rows = n->brickRowLen; b.rowsG = n->brickRows; b.rowCountG = n->brickRowCount;
+      b.listRounds = n->brickRounds; b.listQuads = n->brickQuads;
+      const real_t rBuild = sim->eam_pot.cutoff + n->skinDistance;
+      b.rBuild2 = rBuild * rBuild;
+   } else {
+      // rows per atom: the cutoff sphere at that density + 50 %, a multiple of 8
+      const double rc = sim->eam_pot.cutoff;
+      int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
+      if (rows < 32) rows = 32;
+      if (rows > 256) rows = 256;
+      if (!sim->eam_pot.pairRows) {                             // rows pass 1 leaves for pass 3: [slot][lane of the atom][trip] words
+         const size_t slotsLocal = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
+         sim->eam_pot.pairRows = dalloc<unsigned>(slotsLocal * EAM_ROW_WORDS, false);
+         sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal, false);      // (written by pass 1 before pass 3 reads it; no zeroing that could race with that)
+         sim->eam_pot.pairRowLen = rows;
+      }
+      b.rows = sim->eam_pot.pairRowLen; b.rowsG = sim->eam_pot.pairRows; b.rowCountG = sim->eam_pot.pairRowCount;
+      if (!sim->eam_pot.brickSel) {      // (zeroed on the launch stream, like the cell marks below)
+         sim->eam_pot.brickSel = dalloc<unsigned long long>((size_t)sim->boxes.nLocalBoxes, false);
+         HIP_CHECK(hipMemsetAsync(sim->eam_pot.brickSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(unsigned long long), st));
+      }
+      b.brickSel = sim->eam_pot.brickSel;
    }
-   b.rows = sim->eam_pot.pairRowLen; b.rowsG = sim->eam_pot.pairRows; b.rowCountG = sim->eam_pot.pairRowCount;
    b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
    { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
-   const int group = eamBrickGroupOf(sim, cells_list, num_cells, CTA_CELL);
+   const int group = eamBrickGroupOf(sim, cells_list, num_cells, method);
    if (group) {            // the boundary / interior launch of the overlap mode: whole bricks (a brick with cells of both lists would be staged twice per pass)
       if (!sim->eam_pot.brickGroup || sim->eam_pot.brickGroupBy != b.by || sim->eam_pot.brickGroupBz != b.bz) {
          if (!sim->eam_pot.brickGroup) sim->eam_pot.brickGroup = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
@@ -826,20 +888,39 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
       ForceTimer aux(sim, st, 1);
       hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(num_cells, 256)), dim3(256), 0, st, cells_list, num_cells, sim->eam_pot.cellSel, b.tag);
    }
-   int waves = 4;
-   { const char* e = getenv("COMD_EAM_BRICK_WAVES"); if (e && atoi(e) >= 4 && atoi(e) <= 16) waves = atoi(e); }
-   const size_t lds = eamBrickLdsBytes(STEP, tableDoubles, b.imageCap, b.rows, waves);
+   const int waves = 4;     // EAM_Force_cta_brick is written for 256 threads: __launch_bounds__(256, 4), staging loops of STAGE x 256 tasks
+   if (listed && 3 * (b.by + 2) * (b.bz + 2) * 32 > EAM_BRICK_STAGE_LISTED * 64 * waves) { fprintf(stderr, "eamForce: a brick of 1 x %d x %d cells has more cells around it than a listed launch stages\n", b.by, b.bz); exit(-1); }
+   const size_t lds = eamBrickLdsBytes(STEP, listed, tableDoubles, b.imageCap, b.rows, waves);
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
    const int grid = group ? sim->eam_pot.brickCount[group - 1] : b.geom.g[0] * b.nby * b.nbz;
    if (grid <= 0) return;
-#define COMD_LAUNCH_EAM_BRICK(TAB, SPL) do { \
-      static size_t attrSet = 0; \
-      if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_brick<STEP, TAB, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; } \
-      hipLaunchKernelGGL((EAM_Force_cta_brick<STEP, TAB, SPL>), dim3(grid), dim3(64 * waves), lds, st, a, b); } while (0)
-   if (spline)           COMD_LAUNCH_EAM_BRICK(false, true);
-   else if (tablesInLds) COMD_LAUNCH_EAM_BRICK(true, false);
-   else                  COMD_LAUNCH_EAM_BRICK(false, false);
+#define COMD_LAUNCH_EAM_BRICK(STP, TAB, SPL, LST) do { \
+      allowDynamicLds((const void*)EAM_Force_cta_brick<STP, TAB, SPL, LST>, lds); \
+      hipLaunchKernelGGL((EAM_Force_cta_brick<STP, TAB, SPL, LST>), dim3(grid), dim3(64 * waves), lds, st, a, b); } while (0)
+   if (STEP == 0)        COMD_LAUNCH_EAM_BRICK(0, false, false, true);
+   else if (listed) {
+      if (spline)           COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, true, true);
+      else if (tablesInLds) COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), true, false, true);
+      else                  COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, false, true);
+   } else {
+      if (spline)           COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, true, false);
+      else if (tablesInLds) COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), true, false, false);
+      else                  COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, false, false);
+   }
 #undef COMD_LAUNCH_EAM_BRICK
+   LAUNCH_CHECK();
+}
+
+extern "C" void comdEamBrickStats(SimGpu* sim, int out[3])
+{
+   out[0] = out[1] = out[2] = 0;
+   if (!sim->eam_pot.brickStats) return;
+   int h[2];
+   HIP_CHECK(hipDeviceSynchronize());
+   HIP_CHECK(hipMemcpy(h, sim->eam_pot.brickStats, sizeof h, hipMemcpyDeviceToHost));
+   HIP_CHECK(hipMemset(sim->eam_pot.brickStats + 1, 0, sizeof(int)));
+   int by = sim->eam_pot.brickBy ? sim->eam_pot.brickBy : 4, bz = sim->eam_pot.brickBz ? sim->eam_pot.brickBz : 2;
+   out[0] = h[1]; out[1] = sim->boxes.gridSize[0] * ceilDiv(sim->boxes.gridSize[1], by) * ceilDiv(sim->boxes.gridSize[2], bz); out[2] = sim->eam_pot.brickImageCap;
 }
 
 template <int STEP>
@@ -856,7 +937,11 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
          return;
       }
    }
-   if ((method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat == 2) {
+   if (eamListedBrick(sim, method)) {
+      if (sim->atoms.neighborList.nBuilds == 0) { fprintf(stderr, "the *_nl methods need buildNeighborListGpu before the first force call\n"); exit(-1); }
+      launchEamBrick<STEP>(sim, a, num_cells, cells_list, st, spline, true, method);
+      return;
+   } else if ((method == THREAD_ATOM_NL || method == WARP_ATOM_NL) && sim->atoms.neighborList.slabFormat == 2) {
       NeighborListGpu* n = &sim->atoms.neighborList;
       (void)nlView(sim);
       NlSlabView v; v.list = n->list16; v.count = n->nNeighbors; v.rows = n->slabRows;
@@ -865,12 +950,10 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (lds > 160 * 1024) { fprintf(stderr, "eamForce: %d atoms in a 27-cell stencil do not fit the LDS\n", n->maxSlabAtoms); exit(-1); }
       const int grid = ceilDiv(num_cells, EAM_NL_WAVES * 8);        // each wave walks ~8 consecutive cells
       if (spline) {
-         static size_t attrSet = 0;
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_nl_lds<STEP, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         allowDynamicLds((const void*)EAM_Force_nl_lds<STEP, true>, lds);
          hipLaunchKernelGGL((EAM_Force_nl_lds<STEP, true>), dim3(grid), dim3(64 * EAM_NL_WAVES), lds, st, a, v, n->maxSlabAtoms);
       } else {
-         static size_t attrSet = 0;
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_nl_lds<STEP, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         allowDynamicLds((const void*)EAM_Force_nl_lds<STEP, false>, lds);
          hipLaunchKernelGGL((EAM_Force_nl_lds<STEP, false>), dim3(grid), dim3(64 * EAM_NL_WAVES), lds, st, a, v, n->maxSlabAtoms);
       }
    } else if (method == THREAD_ATOM_NL || method == WARP_ATOM_NL) {
@@ -881,7 +964,8 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       else if (tableBytes <= 32 * 1024) hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, true, false>), dim3(nBlocks), dim3(256), tableBytes, st, a, nl);
       else                              hipLaunchKernelGGL((EAM_Force_thread_atom_nl<STEP, false, false>), dim3(nBlocks), dim3(256), 0, st, a, nl);
    } else if (eamBrickPath(sim, method)) {
-      launchEamBrick<STEP>(sim, a, num_cells, cells_list, st, spline);
+      launchEamBrick<STEP>(sim, a, num_cells, cells_list, st, spline, false, method);
+      return;
    } else if (method == CTA_CELL) {
       // COMD_EAM_CTA=cell: round 2's form, a wave stages the stencil of every cell for itself (nl_kernels.h EAM_Force_cta_cell); kept for A/B runs
       const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
@@ -931,8 +1015,7 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
       const int grid = ceilDiv(num_cells, waves * 8);        // each wave walks ~8 consecutive cells
 #define COMD_LAUNCH_EAM_CTA(TAB, SPL) do { \
-         static size_t attrSet = 0; \
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)EAM_Force_cta_cell<STEP, TAB, SPL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; } \
+         allowDynamicLds((const void*)EAM_Force_cta_cell<STEP, TAB, SPL>, lds); \
          hipLaunchKernelGGL((EAM_Force_cta_cell<STEP, TAB, SPL>), dim3(grid), dim3(64 * waves), lds, st, a, stencil, rows, sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->fuseEmbed, sim->status); } while (0)
       if (spline)           COMD_LAUNCH_EAM_CTA(false, true);
       else if (tablesInLds) COMD_LAUNCH_EAM_CTA(true, false);
@@ -952,7 +1035,7 @@ extern "C" void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, i
 {
    (void)spline;                            /* F(rhobar) is quadratic in both modes (gpu_utility.c:443) */
    if (num_cells <= 0) return;
-   if (sim->fuseEmbed && method == CTA_CELL) return;      /* eamForce1Gpu[Async] has done it for these cells (SimGpu.fuseEmbed) */
+   if (sim->fuseEmbed && (method == CTA_CELL || eamListedBrick(sim, method))) return;      /* eamForce1Gpu[Async] has done it for these cells (SimGpu.fuseEmbed) */
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
    // cta_cell in the overlap mode: pass 1 took whole bricks (launchEamBrick), the embedding follows the same groups over all local cells
    const int group = sim->eam_pot.brickGroup ? eamBrickGroupOf(sim, cells_list, num_cells, method) : 0;
@@ -1241,7 +1324,7 @@ extern "C" void neighborListForceRebuildGpu(SimGpu* sim) { sim->atoms.neighborLi
 extern "C" int neighborListUpdateRequiredGpu(SimGpu* sim)
 {
    NeighborListGpu* n = &sim->atoms.neighborList;
-   if ((!n->list && !n->list16 && !n->pairlist) || n->forceRebuildFlag) return 1;
+   if ((!n->list && !n->list16 && !n->pairlist && !n->brickRows) || n->forceRebuildFlag) return 1;
    hipStream_t st = S(sim->boundary_stream);
    HIP_CHECK(hipMemsetAsync(n->updateRequired, 0, sizeof(int), st));
    hipLaunchKernelGGL(NeighborListUpdateRequired, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
@@ -1265,9 +1348,25 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
       n->nBuilds++;
       return;
    }
-   if (!n->list && !n->list16) { fprintf(stderr, "buildNeighborListGpu: no lists allocated (GpuConfig.skinDistance == 0)\n"); exit(-1); }
+   if (!n->list && !n->list16 && !n->brickRows) { fprintf(stderr, "buildNeighborListGpu: no lists allocated (GpuConfig.skinDistance == 0)\n"); exit(-1); }
    const real_t cutoff = sim->do_eam ? sim->eam_pot.cutoff : sim->lj_pot.cutoff;
    const real_t rBuild = cutoff + n->skinDistance;
+   if (n->slabFormat == 4) {
+      // rows of the brick kernel: the cells were just re-binned, so the image is sized again for the fullest block; STEP 0 sweeps every brick once
+      hipStream_t st = S(sim->boundary_stream);
+      sim->eam_pot.brickImageCap = 0;
+      EamArgs a = makeEamArgs(sim, sim->boxes.nLocalBoxes, nullptr);
+      if (!sim->eam_pot.brickStats) sim->eam_pot.brickStats = dalloc<int>(2);
+      HIP_CHECK(hipMemsetAsync(sim->eam_pot.brickStats, 0, 2 * sizeof(int), st));
+      launchEamBrick<0>(sim, a, sim->boxes.nLocalBoxes, nullptr, st, 0, true, THREAD_ATOM_NL);
+      const size_t bytes = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * sizeof(real_t);
+      HIP_CHECK(hipMemcpyAsync(n->lastR.x, sim->atoms.r.x, bytes, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(n->lastR.y, sim->atoms.r.y, bytes, hipMemcpyDeviceToDevice, st));
+      HIP_CHECK(hipMemcpyAsync(n->lastR.z, sim->atoms.r.z, bytes, hipMemcpyDeviceToDevice, st));
+      n->forceRebuildFlag = 0;
+      n->nBuilds++;
+      return;
+   }
    if (n->slabFormat) {
       hipStream_t st = S(sim->boundary_stream);
       NlSlabView sv; sv.list = n->list16; sv.count = n->nNeighbors; sv.rows = n->slabRows;
@@ -1281,8 +1380,7 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
          if (stencilCap > worst) stencilCap = worst;
          for (;;) {
             const size_t lds = (size_t)EAM_NL_WAVES * eamBuildWaveBytes(stencilCap, n->slabRows);
-            static size_t attrSet = 0;
-            if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)BuildNeighborListCell16, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+            allowDynamicLds((const void*)BuildNeighborListCell16, lds);
             HIP_CHECK(hipMemsetAsync(n->stats, 0, 2 * sizeof(int), st));
             hipLaunchKernelGGL(BuildNeighborListCell16, dim3(ceilDiv(sim->boxes.nLocalBoxes, EAM_NL_WAVES * 8)), dim3(64 * EAM_NL_WAVES), lds, st,
                                sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
@@ -1302,8 +1400,7 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
       {
          // one workgroup per cell, a thread per slot; the LDS holds a whole group of full cells (<= 9 * 512 atoms = 108 KB)
          const size_t lds = (size_t)3 * NL_GROUP_CELLS * sim->maxAtoms * sizeof(real_t);
-         static size_t attrSet = 0;
-         if (lds > attrSet) { HIP_CHECK(hipFuncSetAttribute((const void*)BuildNeighborListSlabs, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attrSet = lds; }
+         allowDynamicLds((const void*)BuildNeighborListSlabs, lds);
          hipLaunchKernelGGL(BuildNeighborListSlabs, dim3(sim->boxes.nLocalBoxes), dim3(sim->maxAtoms), lds, st,
                             sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
                             sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);

@@ -19,9 +19,20 @@
 #pragma once
 #include "nl_kernels.h"
 
+//
+// [round 4] LISTED = true: the Verlet-list method (-m thread_atom_nl -e) on the same machinery.  Between two list builds no atom changes its
+// slot and no cell its occupancy (nl_kernels.h), so the record numbers of a brick's image stay valid for as long as the lists do: the rows
+// are built ONCE per list build (STEP 0: the build sweeps of pass 1 with the cutoff inflated by the skin, nothing evaluated) and both
+// passes of every force evaluation until the next build read them back -- no distance sweep over the 283 stencil candidates, 57 listed
+// neighbours instead, the cutoff decided per pair inside the evaluation (a listed pair outside the cutoff is evaluated at the cutoff with
+// weight 0: branch-free).  Listed rows live per (cell, round of 16 atoms) as [quad of 4 words][64 lanes] 16-byte elements: a wave reads the
+// rows of a round with dense 1 KB loads.  The image of a listed launch always holds the whole block (the numbers must not depend on
+// which cells a launch selects) plus one record FAR_AWAY that pads odd rows.
 #define EAM_BRICK_MAX_CELLS 128           // cells of the staged block: 3 * (BY + 2) * (BZ + 2) <= 128
 #define EAM_BRICK_SR 6                    // records a lane keeps in registers during the build (384 per wave; larger stencils read the LDS)
 #define EAM_BRICK_STAGE 8                 // staging iterations with all loads in flight (256 threads x 8 = 128 cells x 16 slots)
+#define EAM_BRICK_STAGE_LISTED 10         // listed launches stage 32 slots per cell (cells of cutoff + skin hold 14 atoms on average): 256 x 10 = 80 cells x 32 slots
+#define EAM_LIST_WORDS 12                 // words (two 16-bit numbers each) a lane holds of a listed row: 3 quads
 
 struct EamBrickArgs {
    CellGeom geom;                         // local grid (+ -H lookup tables, device pointers)
@@ -36,22 +47,28 @@ struct EamBrickArgs {
    int fuseEmbed;
    int* status;
    int debug;                             // experiments (COMD_EAM_ABLATE): 1 no build sweeps, 2 no pair evaluation
+   // listed launches (Verlet lists): rowsG = [cell][listRounds][listQuads][64 lanes] uint4, rowCountG = [local slots] list lengths
+   int listRounds, listQuads;             // rounds of roundAtoms atoms a cell's capacity makes; 16-byte quads per lane and round (<= 3)
+   real_t rBuild2;                        // STEP 0: (cutoff + skin)^2
+   int* stats;                            // [0] longest list (STEP 0), [1] bricks whose block outgrew the image, counted by STEP 0 / pass 1 (NULL: not counted)
+   unsigned long long* brickSel;          // not listed: [local cells] the selection of its brick pass 1 wrote the cell's rows under; pass 3 must stage for the same (status[3] |= 4)
 };
 
 __host__ __device__ static inline int eamBrickRowStrideL(int rows) { return rows + 2; }      // LDS row stride (entries): one dword of padding walks the atoms' rows over the banks
-// per wave, pass 1 only: [16][stride] rows + [16] counts
-__host__ __device__ static inline size_t eamBrickWaveBytes(int step, int rows)
+// per wave, only where rows are built (pass 1 without lists, STEP 0 with): [16][stride] rows + [16] counts
+__host__ __device__ static inline bool eamBrickBuilds(int step, bool listed) { return listed ? step == 0 : step == 1; }
+__host__ __device__ static inline size_t eamBrickWaveBytes(int step, bool listed, int rows)
 {
-   return step == 1 ? (((size_t)16 * eamBrickRowStrideL(rows) * 2 + 64 + 15) & ~(size_t)15) : 0;
+   return eamBrickBuilds(step, listed) ? (((size_t)16 * eamBrickRowStrideL(rows) * 2 + 64 + 15) & ~(size_t)15) : 0;
 }
 __host__ __device__ static inline size_t eamBrickSharedBytes(int step, int imageCap)
 {
    return (((size_t)(step == 3 ? 4 : 3) * imageCap * sizeof(real_t) + 15) & ~(size_t)15)      // records (+ F' in pass 3)
           + (size_t)(EAM_BRICK_MAX_CELLS + 4) * 4 + (size_t)EAM_BRICK_MAX_CELLS * 4 + 64 + 64;   // offsets, cell ids, scalars, list of selected cells
 }
-static inline size_t eamBrickLdsBytes(int step, size_t tableDoubles, int imageCap, int rows, int waves)
+static inline size_t eamBrickLdsBytes(int step, bool listed, size_t tableDoubles, int imageCap, int rows, int waves)
 {
-   return eamTableBytesAligned(tableDoubles) + eamBrickSharedBytes(step, imageCap) + (size_t)waves * eamBrickWaveBytes(step, rows);
+   return eamTableBytesAligned(tableDoubles) + eamBrickSharedBytes(step, imageCap) + (size_t)waves * eamBrickWaveBytes(step, listed, rows);
 }
 
 __global__ __launch_bounds__(256)
@@ -81,20 +98,25 @@ void ClassifyBrickCells(EamBrickArgs b, const int* __restrict__ marks, int tag, 
    brickClass[bid] = any ? 1 : 2;
 }
 
-template <int STEP, bool LDS_TABLES, bool SPLINE>
+template <int STEP, bool LDS_TABLES, bool SPLINE, bool LISTED>
 __global__ __launch_bounds__(256, 4)
 void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
 {
+   static_assert(STEP != 0 || LISTED, "STEP 0 builds Verlet rows");
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int REC = 3;                                    // doubles per staged atom: x, y, z (24-byte stride); pass 3 keeps F' in an array of its own
    constexpr int SR = EAM_BRICK_SR;
+   constexpr bool BUILDS = LISTED ? STEP == 0 : STEP == 1;   // this launch sweeps the stencil for rows
+   constexpr int SLOT_BITS = LISTED ? 5 : 4, SLOTS = 1 << SLOT_BITS;      // slots of a cell requested before its occupancy is known
+   constexpr int STAGE = LISTED ? EAM_BRICK_STAGE_LISTED : EAM_BRICK_STAGE;
+   constexpr int W = LISTED ? EAM_LIST_WORDS : 8;            // words of a row a lane holds
    const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), nThreads = blockDim.x, nWaves = nThreads >> 6;
    const int nRhoPad = a.rho.n + 3;
    const bool sameGrid = (STEP == 1) && LDS_TABLES && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
    real_t* sRho = (real_t*)ldsRaw;
    real_t* sPhi = sRho + nRhoPad;
    int tableDoubles = 0;
-   if (LDS_TABLES) tableDoubles = (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;
+   if (LDS_TABLES && STEP != 0) tableDoubles = (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;
 
    real_t* __restrict__ sp = (real_t*)(ldsRaw + eamTableBytesAligned(tableDoubles));
    real_t* __restrict__ sd = sp + REC * b.imageCap;          // [imageCap] F' (pass 3)
@@ -102,9 +124,10 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
    int* sBox = sOff + EAM_BRICK_MAX_CELLS + 4;               // [128] cell ids of the block
    int* sMisc = sBox + EAM_BRICK_MAX_CELLS;                  // [16]: 0/1 selection mask, 4 records in the image
    unsigned char* sList = (unsigned char*)(sMisc + 16);      // [64] selected cells of the brick, compacted
-   unsigned short* sHit = (unsigned short*)(sList + 64 + (size_t)wave * eamBrickWaveBytes(STEP, b.rows));      // pass 1: [16][stride] rows under construction
+   unsigned short* sHit = (unsigned short*)(sList + 64 + (size_t)wave * eamBrickWaveBytes(STEP, LISTED, b.rows));      // builds: [16][stride] rows under construction
    const int strideL = eamBrickRowStrideL(b.rows);
-   int* sCnt = (int*)(sHit + 16 * strideL);                  // pass 1: [16] neighbours of the round's atoms
+   int* sCnt = (int*)(sHit + 16 * strideL);                  // builds: [16] neighbours of the round's atoms
+   const real_t rTest2 = (STEP == 0) ? b.rBuild2 : a.rc2;     // what a build sweep keeps
 
    // ---- the brick and its selected cells -------------------------------------------------------------------------------------------
    const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2];
@@ -135,12 +158,19 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
       const bool s = (selMask >> lane) & 1ull;
       if (s) sList[__builtin_amdgcn_mbcnt_hi((unsigned)(selMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)selMask, 0u))] = (unsigned char)lane;
    }
+   // Without lists the image -- and with it every number in the rows -- depends on the selection: pass 3 must stage a cell's brick for the selection
+   // pass 1 staged it for when it wrote the cell's rows.
+   if (!LISTED && b.brickSel && wave == 0 && ((selMask >> lane) & 1ull)) {
+      const int c = comdBoxFromTuple(&b.geom, bx, by0 + lane % b.by, bz0 + lane / b.by);
+      if (STEP == 1) b.brickSel[c] = selMask;
+      else if (b.brickSel[c] != selMask) atomicOr(&b.status[3], 4);
+   }
 
    // ---- ONE round trip for the block: occupancies and records are requested together ------------------------------------------------------
-   // A thread asks for slot s of block cell h (task = 16 h + s) without waiting for the occupancies: the 16 slots of a cell are one 128-byte line
+   // A thread asks for slot s of block cell h (task = SLOTS h + s) without waiting for the occupancies: the 16 slots of a cell are one 128-byte line
    // per array whether they hold atoms or not.  What is not an atom is dropped when the occupancies have arrived and been scanned.
-   real_t lx[EAM_BRICK_STAGE], ly[EAM_BRICK_STAGE], lz[EAM_BRICK_STAGE], ld[EAM_BRICK_STAGE];
-   bool lok[EAM_BRICK_STAGE];
+   real_t lx[STAGE], ly[STAGE], lz[STAGE], ld[STAGE];
+   bool lok[STAGE];
    int myBox = -1;
    auto request = [&](const int k, const int bb, const int s) {      // (32-bit byte offsets: the launcher sends arrays of 4 GiB or more to the other kernel)
       lok[k] = bb >= 0 && s < a.cap;
@@ -166,9 +196,9 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
       };
       if (tid < NH) myBox = plainBox(tid);
 #pragma unroll
-      for (int k = 0; k < EAM_BRICK_STAGE; ++k) {
-         const int task = k * nThreads + tid, h = task >> 4;
-         request(k, h < NH ? plainBox(h) : -1, task & 15);
+      for (int k = 0; k < STAGE; ++k) {
+         const int task = k * nThreads + tid, h = task >> SLOT_BITS;
+         request(k, h < NH ? plainBox(h) : -1, task & (SLOTS - 1));
       }
    } else {
       // every wave works out the cell ids of all 128 block cells (two per lane; -1: outside the grid or in no selected cell's stencil)
@@ -178,14 +208,16 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
             const int xh = h % 3, yh = (h / 3) % HY, zh = h / (3 * HY);
             const int iy = by0 + yh - 1, iz = bz0 + zh - 1;
             if (iy <= gy && iz <= gz) {
-               bool need = false;                             // in the stencil of a selected cell of the brick?
+               bool need = LISTED;                            // in the stencil of a selected cell of the brick?  (listed rows: the whole block, always)
+               if (!LISTED) {
 #pragma unroll
-               for (int dz = -1; dz <= 1; ++dz)
+                  for (int dz = -1; dz <= 1; ++dz)
 #pragma unroll
-                  for (int dy = -1; dy <= 1; ++dy) {
-                     const int cy = yh - 1 + dy, cz = zh - 1 + dz;
-                     if (cy >= 0 && cy < b.by && cz >= 0 && cz < b.bz) need = need || ((selMask >> (cy + b.by * cz)) & 1ull);
-                  }
+                     for (int dy = -1; dy <= 1; ++dy) {
+                        const int cy = yh - 1 + dy, cz = zh - 1 + dz;
+                        if (cy >= 0 && cy < b.by && cz >= 0 && cz < b.bz) need = need || ((selMask >> (cy + b.by * cz)) & 1ull);
+                     }
+               }
                if (need) box = comdBoxFromTuple(&b.geom, bx + xh - 1, iy, iz);
             }
          }
@@ -194,15 +226,15 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
       const int boxLo = blockBox(lane), boxHi = blockBox(64 + lane);
       if (wave < 2) myBox = wave == 0 ? boxLo : boxHi;
 #pragma unroll
-      for (int k = 0; k < EAM_BRICK_STAGE; ++k) {
-         const int task = k * nThreads + tid, h = task >> 4;
+      for (int k = 0; k < STAGE; ++k) {
+         const int task = k * nThreads + tid, h = task >> SLOT_BITS;
          const int fromLo = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxLo), fromHi = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxHi);
-         request(k, h < NH ? (h < 64 ? fromLo : fromHi) : -1, task & 15);
+         request(k, h < NH ? (h < 64 ? fromLo : fromHi) : -1, task & (SLOTS - 1));
       }
    }
    int myCnt = 0;
    if (myBox >= 0) myCnt = a.nAtoms[myBox];
-   if (LDS_TABLES) {
+   if (LDS_TABLES && STEP != 0) {
       if (sameGrid) {
          for (int t = tid; t < nRhoPad; t += nThreads) { sRho[2 * t] = a.phi.values[t]; sRho[2 * t + 1] = a.rho.values[t]; }
       } else {
@@ -224,11 +256,11 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
    }
    __syncthreads();
    const int imageTotal = uniform(sMisc[4]);
-   const bool fits = imageTotal <= b.imageCap;
+   const bool fits = imageTotal + (LISTED ? 1 : 0) <= b.imageCap;
    if (fits) {
 #pragma unroll
-      for (int k = 0; k < EAM_BRICK_STAGE; ++k) {
-         const int task = k * nThreads + tid, h = task >> 4, s = task & 15;
+      for (int k = 0; k < STAGE; ++k) {
+         const int task = k * nThreads + tid, h = task >> SLOT_BITS, s = task & (SLOTS - 1);
          if (lok[k]) {
             const int off = sOff[h], n = sOff[h + 1] - off;
             if (s < n) {
@@ -238,23 +270,29 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
             }
          }
       }
-      // cells of more than 16 atoms: blocking copies
-      for (int task = tid; task < NH * 16; task += nThreads) {
-         const int h = task >> 4, off = sOff[h], n = sOff[h + 1] - off;
-         for (int s = (task & 15) + 16; s < n; s += 16) {
+      // cells of more than SLOTS atoms: blocking copies
+      for (int task = tid; task < NH * SLOTS; task += nThreads) {
+         const int h = task >> SLOT_BITS, off = sOff[h], n = sOff[h + 1] - off;
+         for (int s = (task & (SLOTS - 1)) + SLOTS; s < n; s += SLOTS) {
             const size_t o = (size_t)sBox[h] * a.cap + s;
             real_t* r = sp + REC * (off + s);
             r[0] = a.rx[o]; r[1] = a.ry[o]; r[2] = a.rz[o];
             if (STEP == 3) sd[off + s] = a.dfEmbed[o];
          }
       }
-   }
+      if (LISTED && tid == 0) {                              // the record that pads odd rows: never inside a cutoff, F' = 0
+         sp[REC * imageTotal] = FAR_AWAY; sp[REC * imageTotal + 1] = FAR_AWAY; sp[REC * imageTotal + 2] = FAR_AWAY;
+         if (STEP == 3) sd[imageTotal] = R(0.0);
+      }
+   } else if (STEP != 3 && b.stats && tid == 0) atomicAdd(&b.stats[1], 1);      // bricks that take the thread-per-atom form (comdEamBrickStats)
    __syncthreads();
    if (b.debug & 4) return;
 
-   // atoms per round: a lane holds at most 8 words = 16 entries of a row, so an atom needs ceil(rows / 16) lanes
-   const int roundAtoms = 64 / ((b.rows + 15) / 16) < 16 ? 64 / ((b.rows + 15) / 16) : 16;
+   // atoms per round: a lane holds at most W words = 2 W entries of a row, so an atom needs ceil(rows / 2 W) lanes
+   const int lanesMin = (b.rows + 2 * W - 1) / (2 * W);
+   const int roundAtoms = 64 / lanesMin < 16 ? 64 / lanesMin : 16;
    bool over = false;
+   int longest = 0;
 
    // geometry of a round: nRound atoms, L lanes each; lane = L * ia + q
    auto roundOf = [&](const int ni, const int i0, int& nRound, int& L, int& ia, int& q) {
@@ -264,22 +302,32 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
       ia = (lane * ((65536 + L - 1) / L)) >> 16;             // lane / L (exact for lane < 64)
       q = lane - ia * L;
    };
-   // A ROW of n entries is dealt to the atom's L lanes in pairs: pair p = entries 2p, 2p+1 goes to lane p % L as its word p / L (trip).  In memory a lane's
-   // words are contiguous -- [slot][lane q][8 words] -- so pass 3 asks for them with two 16-byte loads, the row length beside them, before it knows the length.
-   struct Pre3 { uint4 lo, hi; int n; real_t f0x, f0y, f0z; };
+   // A ROW of n entries is dealt to the atom's L lanes in pairs: pair p = entries 2p, 2p+1 goes to lane p % L as its word p / L (trip).
+   //   not listed: in memory a lane's words are contiguous -- [slot][lane q][8 words] -- so pass 3 asks for them with two 16-byte loads, the row length
+   //               beside them, before it knows the length;
+   //   listed:     per (cell, round) [quad][64 lanes] 16-byte elements, a lane's words 4 j .. 4 j + 3 in quad j.
+   struct Pre3 { uint4 lo, hi, ex; int n; real_t f0x, f0y, f0z; };
    auto fetch3 = [&](const int iBox, const int ni, const int i0, Pre3& p) {
       int nRound, L, ia, q; roundOf(ni, i0, nRound, L, ia, q);
-      p.lo = make_uint4(0u, 0u, 0u, 0u); p.hi = p.lo; p.n = 0; p.f0x = p.f0y = p.f0z = R(0.0);
+      p.lo = make_uint4(0u, 0u, 0u, 0u); p.hi = p.lo; p.ex = p.lo; p.n = 0; p.f0x = p.f0y = p.f0z = R(0.0);
       if (i0 + ia < ni && ia < nRound) {
          const size_t cellSlot = (size_t)iBox * a.cap;
          const unsigned ii = (unsigned)(i0 + ia);
          p.n = (b.rowCountG + cellSlot)[ii];
-         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG + cellSlot * EAM_ROW_WORDS);
-         p.lo = src[ii * (EAM_ROW_WORDS / 4) + 2u * q]; p.hi = src[ii * (EAM_ROW_WORDS / 4) + 2u * q + 1u];
+         if (LISTED) {
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
+            p.lo = src[0];
+            if (b.listQuads > 1) p.hi = src[64];
+            if (b.listQuads > 2) p.ex = src[128];
+         } else {
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG + cellSlot * EAM_ROW_WORDS);
+            p.lo = src[ii * (EAM_ROW_WORDS / 4) + 2u * q]; p.hi = src[ii * (EAM_ROW_WORDS / 4) + 2u * q + 1u];
+         }
          // pass 3 adds to the forces of pass 1: ask for them now, a whole cell of arithmetic before they are needed
-         if (q == 0) { p.f0x = (a.fx + cellSlot)[ii]; p.f0y = (a.fy + cellSlot)[ii]; p.f0z = (a.fz + cellSlot)[ii]; }
+         if (STEP == 3 && q == 0) { p.f0x = (a.fx + cellSlot)[ii]; p.f0y = (a.fy + cellSlot)[ii]; p.f0z = (a.fz + cellSlot)[ii]; }
       }
    };
+   constexpr bool FETCHES = STEP == 3 || (LISTED && STEP == 1);      // rows come from memory
    // ---- the waves take the brick's selected cells in turn: wave w the cells w, w + nWaves, ... -----------------------------------------------
    auto cellHeader = [&](const int pick, int& iBox, int& ownStart, int& ni, int& yh, int& zh) {
       const int cl = sList[pick];
@@ -288,17 +336,17 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
       iBox = uniform(sBox[hc]); ownStart = uniform(sOff[hc]); ni = uniform(sOff[hc + 1]) - ownStart;
    };
    Pre3 pre;
-   pre.lo = make_uint4(0u, 0u, 0u, 0u); pre.hi = pre.lo; pre.n = 0; pre.f0x = pre.f0y = pre.f0z = R(0.0);
-   if (STEP == 3 && fits && wave < nSel) { int iBox, os, ni, yh, zh; cellHeader(wave, iBox, os, ni, yh, zh); fetch3(iBox, ni, 0, pre); }
+   pre.lo = make_uint4(0u, 0u, 0u, 0u); pre.hi = pre.lo; pre.ex = pre.lo; pre.n = 0; pre.f0x = pre.f0y = pre.f0z = R(0.0);
+   if (FETCHES && fits && wave < nSel) { int iBox, os, ni, yh, zh; cellHeader(wave, iBox, os, ni, yh, zh); fetch3(iBox, ni, 0, pre); }
    for (int pick = wave; pick < nSel; pick += nWaves) {
       int iBox, ownStart, ni, yh, zh;
       cellHeader(pick, iBox, ownStart, ni, yh, zh);
-      if (!fits) {      // a block larger than the LDS image (small boxes have larger cells): thread-per-atom form, same tables
-         eamCellDirect<STEP, SPLINE>(a, iBox, lane, rhoT, phiT, sameGrid, b.fuseEmbed);
+      if (!fits) {      // a block larger than the LDS image (small boxes have larger cells): thread-per-atom form, same tables (needs no rows: STEP 0 leaves none)
+         if (STEP != 0) eamCellDirect<STEP == 0 ? 1 : STEP, SPLINE>(a, iBox, lane, rhoT, phiT, sameGrid, b.fuseEmbed);
          continue;
       }
       Pre3 cur = pre;
-      if (STEP == 3 && pick + nWaves < nSel) { int nb, nos, nni, nyh, nzh; cellHeader(pick + nWaves, nb, nos, nni, nyh, nzh); fetch3(nb, nni, 0, pre); }
+      if (FETCHES && pick + nWaves < nSel) { int nb, nos, nni, nyh, nzh; cellHeader(pick + nWaves, nb, nos, nni, nyh, nzh); fetch3(nb, nni, 0, pre); }
       if (ni == 0) continue;
       const size_t cellSlot = (size_t)iBox * a.cap;          // wave-uniform: the cell's arrays are addressed base + 32-bit lane offset
       // the stencil: three runs of records, one per z plane (rows yh-1 .. yh+1 of a plane lie back to back)
@@ -308,7 +356,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
       const int l0 = rE0 - rS0, l01 = l0 + (rE1 - rS1), total = l01 + (rE2 - rS2);
       auto recOf = [&](const int t) { return t < l0 ? rS0 + t : t < l01 ? rS1 + (t - l0) : rS2 + (t - l01); };
 
-      // pass 1, build of a round's rows: two atoms at a time against ALL the cell's stencil records -- lane = record; for round 0 the
+      // build of a round's rows: two atoms at a time against ALL the cell's stencil records -- lane = record; for round 0 the
       // records sit in registers (read from the image once per cell), the atoms' positions are broadcast reads -- ballot + mbcnt append
       // the hits, in record order, to the atoms' rows
       auto buildRound = [&](const int i0, const bool fromRegs, const int (&rec)[SR], const real_t (&vx)[SR], const real_t (&vy)[SR], const real_t (&vz)[SR]) {
@@ -326,8 +374,8 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
                const real_t r2A = ax * ax + ay * ay + az * az, r2B = bx_ * bx_ + by_ * by_ + bz_ * bz_;
                // Lanes past the stencil hold a record at FAR_AWAY.  The ballot of a compare IS the compare's mask (the ballot of an and-ed bool costs
                // a cndmask and a second compare), and inverse_ballot turns the and-ed mask into the exec mask of the append without a VALU instruction.
-               const unsigned long long mA = __builtin_amdgcn_ballot_w64(r2A <= a.rc2) & __builtin_amdgcn_ballot_w64(r != recA);
-               const unsigned long long mB = __builtin_amdgcn_ballot_w64(r2B <= a.rc2) & __builtin_amdgcn_ballot_w64(r != recB);
+               const unsigned long long mA = __builtin_amdgcn_ballot_w64(r2A <= rTest2) & __builtin_amdgcn_ballot_w64(r != recA);
+               const unsigned long long mB = __builtin_amdgcn_ballot_w64(r2B <= rTest2) & __builtin_amdgcn_ballot_w64(r != recB);
                const bool hitA = __builtin_amdgcn_inverse_ballot_w64(mA), hitB = __builtin_amdgcn_inverse_ballot_w64(mB);
                const int kA = nA + __builtin_amdgcn_mbcnt_hi((unsigned)(mA >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mA, 0u));
                const int kB = nB + __builtin_amdgcn_mbcnt_hi((unsigned)(mB >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mB, 0u));
@@ -351,7 +399,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
             if (lane == 0) { sCnt[pa] = nA; sCnt[pa + 1] = nB; }
          }
       };
-      if (STEP == 1) {
+      if (BUILDS) {
          int rec[SR]; real_t vx[SR], vy[SR], vz[SR];
 #pragma unroll
          for (int g = 0; g < SR; ++g) {
@@ -370,9 +418,9 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          const int recI = ownStart + (int)ii;
          const real_t xi = sp[REC * recI], yi = sp[REC * recI + 1], zi = sp[REC * recI + 2];
          const real_t dfi = (STEP == 3) ? sd[recI] : R(0.0);
-         if (STEP == 3 && i0 != 0) fetch3(iBox, ni, i0, cur);        // later rounds of a cell of more than 16 atoms: blocking
+         if (FETCHES && i0 != 0) fetch3(iBox, ni, i0, cur);          // later rounds of a cell of more than 16 atoms: blocking
          int n = 0;
-         if (STEP == 1) {
+         if (BUILDS) {
             if (i0 != 0) {                                   // (round 0 was built above)
                const int rec[SR] = { 0, 0, 0, 0, 0, 0 }; const real_t v0[SR] = { R(0.0), R(0.0), R(0.0), R(0.0), R(0.0), R(0.0) };
                __builtin_amdgcn_wave_barrier();
@@ -387,28 +435,59 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          if (b.debug & 2) n = 0;
          const int nPairs = (n + 1) >> 1;
          const unsigned short* __restrict__ myRow = sHit + (have ? ia : 0) * strideL;
-         unsigned wReg[8] = { cur.lo.x, cur.lo.y, cur.lo.z, cur.lo.w, cur.hi.x, cur.hi.y, cur.hi.z, cur.hi.w };
+         unsigned wReg[12] = { cur.lo.x, cur.lo.y, cur.lo.z, cur.lo.w, cur.hi.x, cur.hi.y, cur.hi.z, cur.hi.w, cur.ex.x, cur.ex.y, cur.ex.z, cur.ex.w };
+
+         if (STEP == 0) {
+            // ---- list build: hand the round's rows to the force passes.  Pair p of an atom's row is word p / L of its lane p % L; what lies beyond the row
+            // names the far-away record (imageTotal), so the evaluation needs no lengths inside a word.
+            longest = n > longest ? n : longest;
+            const unsigned pad = (unsigned)imageTotal;
+#pragma unroll
+            for (int u = 0; u < W; ++u) {
+               const int pr = u * L + q;
+               unsigned w = pad | (pad << 16);
+               if (have && pr < nPairs) {
+                  const unsigned e0 = myRow[2 * pr], e1 = 2 * pr + 1 < n ? (unsigned)myRow[2 * pr + 1] : pad;
+                  w = e0 | (e1 << 16);
+               }
+               wReg[u] = w;
+            }
+            uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
+            dst[0] = make_uint4(wReg[0], wReg[1], wReg[2], wReg[3]);
+            if (b.listQuads > 1) dst[64] = make_uint4(wReg[4], wReg[5], wReg[6], wReg[7]);
+            if (b.listQuads > 2) dst[128] = make_uint4(wReg[8], wReg[9], wReg[10], wReg[11]);
+            if (lane < nRound) (b.rowCountG + cellSlot)[(unsigned)(i0 + lane)] = (unsigned short)(sCnt[lane] < b.rows ? sCnt[lane] : b.rows);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+         }
 
          real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0);
-         // two pairs per trip, branch-free (a missing second pair is evaluated at r = cutoff and weighted 0)
+         // two pairs per trip, branch-free.  Not listed: a missing second pair is evaluated at r = cutoff and weighted 0.  Listed: every number names a
+         // record (the far-away one past the end of a row); a pair outside the cutoff is evaluated AT the cutoff and enters with weight 0.
          auto evalTrip = [&](const int j0, const int j1, const bool h1) {
             const real_t* r0 = sp + REC * j0; const real_t* r1 = sp + REC * j1;
             const real_t dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
             const real_t dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
-            const real_t s0 = dx0*dx0 + dy0*dy0 + dz0*dz0;
-            const real_t s1 = h1 ? dx1*dx1 + dy1*dy1 + dz1*dz1 : a.rc2;
+            real_t s0 = dx0*dx0 + dy0*dy0 + dz0*dz0;
+            real_t s1 = (LISTED || h1) ? dx1*dx1 + dy1*dy1 + dz1*dz1 : a.rc2;
+            real_t w0 = R(1.0), w1 = R(1.0);
+            if (LISTED) {
+               w0 = s0 <= a.rc2 ? R(1.0) : R(0.0); w1 = s1 <= a.rc2 ? R(1.0) : R(0.0);
+               s0 = minR(s0, a.rc2); s1 = minR(s1, a.rc2);
+            }
             real_t rho0, drho0, dphi0, rho1, drho1, dphi1;
             if (SPLINE) {                                    // -P: cubic splines in r^2 give (1/r) d/dr directly, no square root
                interpolateSpline(a.rhoS, s0, rho0, drho0); interpolateSpline(a.rhoS, s1, rho1, drho1);
                if (STEP == 1) {
                   real_t phi0, phi1;
                   interpolateSpline(a.phiS, s0, phi0, dphi0); interpolateSpline(a.phiS, s1, phi1, dphi1);
-                  e += phi0 + (h1 ? phi1 : R(0.0));
-                  rb += rho0 + (h1 ? rho1 : R(0.0));
+                  if (LISTED) { e = fmaR(phi0, w0, e); e = fmaR(phi1, w1, e); rb = fmaR(rho0, w0, rb); rb = fmaR(rho1, w1, rb); }
+                  else { e += phi0 + (h1 ? phi1 : R(0.0)); rb += rho0 + (h1 ? rho1 : R(0.0)); }
                } else {
                   dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
                }
-               dphi1 = h1 ? dphi1 : R(0.0);
+               if (LISTED) { dphi0 *= w0; dphi1 *= w1; }
+               else dphi1 = h1 ? dphi1 : R(0.0);
             } else {
                const real_t ir0 = rsqrtR(s0), ir1 = rsqrtR(s1);
                const real_t d0 = s0 * ir0, d1 = s1 * ir1;
@@ -416,25 +495,26 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
                   real_t phi0, phi1;
                   if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
                   else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
-                  e += phi0 + (h1 ? phi1 : R(0.0));
-                  rb += rho0 + (h1 ? rho1 : R(0.0));
+                  if (LISTED) { e = fmaR(phi0, w0, e); e = fmaR(phi1, w1, e); rb = fmaR(rho0, w0, rb); rb = fmaR(rho1, w1, rb); }
+                  else { e += phi0 + (h1 ? phi1 : R(0.0)); rb += rho0 + (h1 ? rho1 : R(0.0)); }
                } else {
                   interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
                   dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
                }
-               dphi0 = dphi0 * ir0; dphi1 = h1 ? dphi1 * ir1 : R(0.0);
+               if (LISTED) { dphi0 = dphi0 * (ir0 * w0); dphi1 = dphi1 * (ir1 * w1); }
+               else { dphi0 = dphi0 * ir0; dphi1 = h1 ? dphi1 * ir1 : R(0.0); }
             }
             fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
             fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
          };
-         // the lane's pairs: q, q + L, q + 2L, ... below nPairs, one per trip (rows <= 16 L: at most 8 trips)
+         // the lane's pairs: q, q + L, q + 2L, ... below nPairs, one per trip (rows <= 2 W L: at most W trips)
 #pragma unroll
-         for (int u = 0; u < 8; ++u) {                       // (unrolled: the words sit in, or go to, registers)
+         for (int u = 0; u < W; ++u) {                       // (unrolled: the words sit in, or go to, registers)
             const int pr = u * L + q;
             if (pr < nPairs) {
-               if (STEP == 1) wReg[u] = *reinterpret_cast<const unsigned*>(myRow + 2 * pr);      // entries 2 pr, 2 pr + 1
+               if (BUILDS) wReg[u] = *reinterpret_cast<const unsigned*>(myRow + 2 * pr);      // entries 2 pr, 2 pr + 1
                const bool h1 = 2 * pr + 1 < n;
-               evalTrip((int)(wReg[u] & 0xffffu), h1 ? (int)(wReg[u] >> 16) : recI, h1);
+               evalTrip((int)(wReg[u] & 0xffffu), (LISTED || h1) ? (int)(wReg[u] >> 16) : recI, h1);
             }
          }
          // The L lanes of an atom are consecutive: a shift-down tree adds them into the first (quad-permute DPP when L is 4).  One ds_bpermute address
@@ -468,7 +548,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
             pR = r - ri;
             pv0 = a.f.values[it]; pv1 = a.f.values[it + 1]; pv2 = a.f.values[it + 2]; pv3 = a.f.values[it + 3];
          }
-         if (STEP == 1) {
+         if (BUILDS) {
             // hand the lane's words to pass 3 (the second 16 bytes only when a trip beyond the fourth was made), and the row lengths
             if (have) {
                uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG + cellSlot * EAM_ROW_WORDS) + ii * (EAM_ROW_WORDS / 4) + 2u * (unsigned)q;
@@ -493,5 +573,10 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          __builtin_amdgcn_wave_barrier();
       }
    }
-   if (__builtin_amdgcn_ballot_w64(over) != 0ull && lane == 0) atomicOr(&b.status[3], 1);
+   if (__builtin_amdgcn_ballot_w64(over) != 0ull && lane == 0) atomicOr(&b.status[3], LISTED ? 2 : 1);
+   if (STEP == 0) {
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(longest, m); longest = o > longest ? o : longest; }
+      if (lane == 0 && longest > 0) atomicMax(&b.stats[0], longest);
+   }
 }

@@ -94,6 +94,11 @@ typedef struct EamPotentialGpu {
    int     brickCount[2], brickListStride;
    int*    cellSel;                    /* device [nLocalBoxes] */
    int     selTag;                     /* host: tag of the last list launch */
+   /* [round 4] per cell, the selection (64-bit mask of the brick's cells) its brick was staged for when pass 1 wrote the cell's rows; pass 3 of the same force evaluation must be launched over
+    * the same partition of the cells -- the 16-bit numbers in pairRows index an image whose composition depends on it -- and raises status[3] bit 2 otherwise */
+   unsigned long long* brickSel;       /* device [nLocalBoxes] */
+   int*    brickStats;                 /* device [2]: {longest Verlet row of the last list build, bricks that took the thread-per-atom form since the last comdEamBrickStats} */
+   int     brickBy, brickBz;           /* host: the brick shape of this simulation (fixed by the first launch: rows index the image of that shape) */
 } EamPotentialGpu;
 
 /* gpu_types.h:98-112 */
@@ -119,7 +124,9 @@ typedef struct NeighborListGpu {
    /* LJ (cells of <= 512 slots): the list is kept per group of stencil cells (the 3 x-planes of 9 cells) as 16-bit indices into the
     * LDS staging of that group: list16[((c*3 + g)*slabRows + k)*maxAtoms + i], nNeighbors[(c*3 + g)*maxAtoms + i]; `list` is unused */
    int    slabFormat;                  /* 0: `list` of global slots; 1: LJ slab lists; 2: EAM, 16-bit record numbers into a wave's staging of the
-                                        * whole 27-cell stencil: list16[(c*slabRows + k)*maxAtoms + i], nNeighbors[c*maxAtoms + i] */
+                                        * whole 27-cell stencil: list16[(c*slabRows + k)*maxAtoms + i], nNeighbors[c*maxAtoms + i] (COMD_EAM_NL=lds);
+                                        * 4: EAM, rows of the brick kernel (hip/eam_brick_kernels.h, the default since round 4): 16-bit record numbers in the
+                                        * LDS image of the atom's brick, per (cell, round of brickRoundAtoms atoms) [brickQuads][64 lanes] 16-byte elements */
    unsigned short* list16;
    int    slabRows;
    int*   stats;                       /* device [2]: {atoms in the largest group, fullest cell} at the last build */
@@ -128,6 +135,9 @@ typedef struct NeighborListGpu {
    unsigned* pairlist;                 /* device [nLocalBoxes * pairlistWaves * 9 slabs * 8 words] */
    int    pairlistWaves;               /* waves per cell the bits are laid out for */
    int    pairlistBuildId;             /* host: nBuilds value the bits were generated for (!= nBuilds: the next force call generates) */
+   unsigned* brickRows;                /* slabFormat 4: device [nLocalBoxes][brickRounds][brickQuads][64] uint4 */
+   unsigned short* brickRowCount;      /* slabFormat 4: device [nLocalBoxes * maxAtoms] list lengths */
+   int    brickRowLen, brickRounds, brickQuads, brickRoundAtoms;
    int    forceRebuildFlag;            /* host: the next neighborListUpdateRequiredGpu answers 1 without looking */
    int    nBuilds;                     /* host: builds since AllocateGpu */
 } NeighborListGpu;
@@ -284,6 +294,14 @@ void eamForce3Gpu(SimGpu* sim, int method, int spline);
 void eamForce1GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline);
 void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline);
 void eamForce3GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, comdStream_t stream, int spline);
+/* CONTRACT of the cta_cell passes (and of thread_atom_nl with brick rows): eamForce3Gpu[Async] must cover the cells with the same partition as the
+ * eamForce1Gpu[Async] calls of the same force evaluation -- all local cells in one call, or boundary_cells and interior_cells (the lists given to
+ * SetBoundaryCells; each launch then takes WHOLE bricks of 1 x 4 x 2 cells: every cell of a brick that holds a boundary cell goes with the boundary
+ * launch), or the same other cell lists in both passes.  Pass 1 records the selection it staged every brick for and pass 3 compares: a mismatch raises
+ * status[3] bit 2 and comdCheckStatus / comdPollStatus stop the run.  (With Verlet rows the numbering does not depend on the selection.)
+ * comdEamBrickStats: {bricks that took the thread-per-atom fall-back since the last call (their block outgrew the LDS image), bricks per launch over all
+ * cells, records the image holds}; a non-zero first number after a re-size means a density the image cannot hold. */
+void comdEamBrickStats(SimGpu* sim, int out[3]);
 /* updateNeighborsGpu[Async], gpu_kernels.cu:251-279: the reference materialises 27*MAXATOMS neighbour
  * offsets per cell for its cta_cell/warp_atom EAM kernels; ours gather from the cell table directly,
  * so these are no-ops kept for link compatibility. */
