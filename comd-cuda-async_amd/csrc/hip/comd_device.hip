@@ -328,7 +328,9 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
          nl->nNeighbors = dalloc<int>(localSlots);
       }
       nl->lastR.x = dalloc<real_t>(localSlots); nl->lastR.y = dalloc<real_t>(localSlots); nl->lastR.z = dalloc<real_t>(localSlots);
-      nl->updateRequired = dalloc<int>(1);
+      HIP_CHECK(hipHostMalloc((void**)&nl->updateRequiredHost, 64, hipHostMallocDefault));      // pinned: written by kernels, read by the host
+      *nl->updateRequiredHost = 0;
+      HIP_CHECK(hipHostGetDevicePointer((void**)&nl->updateRequired, nl->updateRequiredHost, 0));
       nl->forceRebuildFlag = 1; nl->nBuilds = 0;
    }
    sim->nAtomsPrev = dalloc<int>(cfg->nTotalBoxes);
@@ -415,7 +417,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->eam_pot.rhobar, sim->eam_pot.dfEmbed, sim->nAtomsPrev, sim->cellDirty, sim->status, sim->reduceBuf,
                     sim->boundary_cells, sim->interior_cells, sim->boundary1_cells,
                     sim->atoms.neighborList.list, sim->atoms.neighborList.nNeighbors, sim->atoms.neighborList.lastR.x,
-                    sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z, sim->atoms.neighborList.updateRequired,
+                    sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
                     sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->eam_pot.brickGroup, sim->eam_pot.brickList, sim->eam_pot.brickSel, sim->eam_pot.brickStats,
@@ -423,6 +425,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->statusEvent) (void)hipEventDestroy((hipEvent_t)sim->statusEvent);
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
+   if (sim->atoms.neighborList.updateRequiredHost) HIP_CHECK(hipHostFree(sim->atoms.neighborList.updateRequiredHost));
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
    if (sim->interior_stream) HIP_CHECK(hipStreamDestroy(S(sim->interior_stream)));
    memset(sim, 0, sizeof(*sim));
@@ -805,6 +808,98 @@ static void eamBrickSizeImage(SimGpu* sim, const EamBrickArgs& b, hipStream_t st
    sim->eam_pot.brickImageCap = cap;
 }
 
+// Verlet rows: the brick lists of a list build.  The occupancies are final (the atom exchange has run) and frozen until the next build, so the host can
+// look at every block once: the image is sized for what the passes can keep four workgroups per CU with, a brick whose block would outgrow it is listed as
+// its two z halves (eam_brick_kernels.h), and the boundary / interior launches of the overlap mode get their lists of whole bricks here as well.
+static size_t eamBrickTableDoubles(const SimGpu* sim, int step, int spline)
+{
+   const EamPotentialGpu& e = sim->eam_pot;
+   if (step == 0 || spline || eamCtaTableBytes(step, e.rho.n, e.phi.n) > 32 * 1024) return 0;
+   const bool sameGrid = e.phi.n == e.rho.n && e.phi.x0 == e.rho.x0 && e.phi.invDx == e.rho.invDx;
+   return step == 1 ? (size_t)2 * (e.rho.n + 3) + (sameGrid ? 0 : (e.phi.n + 3 - (e.rho.n + 3))) : (size_t)(e.rho.n + 3);
+}
+
+static void eamBrickBuildLists(SimGpu* sim, hipStream_t st, int spline)
+{
+   NeighborListGpu* n = &sim->atoms.neighborList;
+   EamBrickArgs b;
+   eamBrickGeometry(sim, true, &b);
+   const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2], nBricks = gx * b.nby * b.nbz;
+   std::vector<int> counts((size_t)sim->boxes.nTotalBoxes), lookup, boundary((size_t)(sim->boundary_cells ? sim->n_boundary_cells : 0));
+   HIP_CHECK(hipMemcpyAsync(counts.data(), sim->boxes.nAtoms, counts.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+   if (sim->boxes.boxIDLookUp) {
+      lookup.resize((size_t)sim->boxes.nLocalBoxes);
+      HIP_CHECK(hipMemcpyAsync(lookup.data(), sim->boxes.boxIDLookUp, lookup.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+   }
+   if (!boundary.empty()) HIP_CHECK(hipMemcpyAsync(boundary.data(), sim->boundary_cells, boundary.size() * sizeof(int), hipMemcpyDeviceToHost, st));
+   HIP_CHECK(hipStreamSynchronize(st));
+   CellGeom hg = b.geom; hg.lookup = lookup.empty() ? nullptr : lookup.data(); hg.reverse = nullptr;
+   // atoms of the three x cells around (x, y, z), y and z from -1 to g
+   std::vector<int> row3((size_t)gx * (gy + 2) * (gz + 2));
+   auto r3 = [&](int x, int y, int z) -> int& { return row3[(size_t)x + (size_t)gx * ((y + 1) + (size_t)(gy + 2) * (z + 1))]; };
+   for (int z = -1; z <= gz; ++z) for (int y = -1; y <= gy; ++y) for (int x = 0; x < gx; ++x)
+      r3(x, y, z) = counts[comdBoxFromTuple(&hg, x - 1, y, z)] + counts[comdBoxFromTuple(&hg, x, y, z)] + counts[comdBoxFromTuple(&hg, x + 1, y, z)];
+   // records in the image of the brick part [z0, z0 + nz) of brick (x, byI, bzI): the kernel stages rows y0-1 .. y0+by and planes z0-1 .. z0+nz that lie inside -1 .. g
+   auto blockAtoms = [&](int x, int byI, int z0, int nz) {
+      long sum = 0;
+      for (int z = z0 - 1; z <= z0 + nz && z <= gz; ++z)
+         for (int y = byI * b.by - 1; y <= byI * b.by + b.by && y <= gy; ++y) sum += r3(x, y, z);
+      return sum;
+   };
+   std::vector<long> whole((size_t)nBricks);
+   long fullest = 0;
+   for (int i = 0; i < nBricks; ++i) {
+      const int x = i % gx, byI = (i / gx) % b.nby, bzI = i / (gx * b.nby);
+      whole[i] = blockAtoms(x, byI, bzI * b.bz, b.bz);
+      if (whole[i] > fullest) fullest = whole[i];
+   }
+   // the largest image that leaves four workgroups per CU (160 KB of LDS in 1280-byte granules) in pass 1 and in pass 3
+   const int waves = 4;
+   auto perCu = [&](int step, int cap) {
+      const size_t lds = eamBrickLdsBytes(step, true, eamBrickTableDoubles(sim, step, spline), cap, n->brickRowLen, waves);
+      return lds > 160 * 1024 ? 0 : (int)(160 * 1024 / (((lds + 1279) / 1280) * 1280));
+   };
+   int capFull = (((int)fullest + 1 + 7) / 8) * 8;            // (+ 1: the far-away record; nothing moves between builds, so no head-room)
+   if (capFull < 256) capFull = 256;
+   int cap = capFull;
+   if (cap <= 4096 && (perCu(1, cap) < 4 || perCu(3, cap) < 4) && b.bz % 2 == 0) {
+      int fit = cap;
+      while (fit > 256 && (perCu(1, fit) < 4 || perCu(3, fit) < 4)) fit -= 8;
+      long split = 0;
+      for (int i = 0; i < nBricks; ++i) split += whole[i] + 1 > fit;
+      if (split * 10 <= nBricks) cap = fit;                  // worth it while at most one brick in ten is staged twice
+   }
+   if (cap > 4096) cap = 4096;
+   { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) cap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force halves and the fall-back
+   sim->eam_pot.brickImageCap = cap;
+   // the lists: [0, stride) bricks that hold a boundary cell, [stride, 2 stride) the others, [2 stride, 3 stride) all of them; brick order, halves adjacent
+   std::vector<char> isBoundary((size_t)sim->boxes.nLocalBoxes, 0);
+   for (int c : boundary) if (c >= 0 && c < sim->boxes.nLocalBoxes) isBoundary[c] = 1;
+   const int stride = 2 * nBricks;
+   std::vector<int> lists((size_t)3 * stride, 0), group((size_t)sim->boxes.nLocalBoxes, 2);
+   int cnt[3] = { 0, 0, 0 };
+   for (int i = 0; i < nBricks; ++i) {
+      const int x = i % gx, by0 = ((i / gx) % b.nby) * b.by, bz0 = (i / (gx * b.nby)) * b.bz;
+      bool any = false;
+      for (int dz = 0; dz < b.bz; ++dz) for (int dy = 0; dy < b.by; ++dy)
+         if (by0 + dy < gy && bz0 + dz < gz) any = any || isBoundary[comdBoxFromTuple(&hg, x, by0 + dy, bz0 + dz)];
+      for (int dz = 0; dz < b.bz; ++dz) for (int dy = 0; dy < b.by; ++dy)
+         if (by0 + dy < gy && bz0 + dz < gz) group[comdBoxFromTuple(&hg, x, by0 + dy, bz0 + dz)] = any ? 1 : 2;
+      const int g = any ? 0 : 1;
+      const bool halves = whole[i] + 1 > cap && b.bz % 2 == 0 && bz0 + b.bz / 2 < gz;      // (an upper half outside the grid would be an empty workgroup)
+      const int e[2] = { halves ? i | (1 << 28) : i, i | (2 << 28) };
+      for (int k = 0; k < (halves ? 2 : 1); ++k) { lists[(size_t)g * stride + cnt[g]++] = e[k]; lists[(size_t)2 * stride + cnt[2]++] = e[k]; }
+   }
+   if (sim->eam_pot.brickList && sim->eam_pot.brickListStride != stride) { HIP_CHECK(hipFree(sim->eam_pot.brickList)); sim->eam_pot.brickList = nullptr; }
+   if (!sim->eam_pot.brickList) sim->eam_pot.brickList = dalloc<int>((size_t)3 * stride, false);
+   if (!sim->eam_pot.brickGroup) sim->eam_pot.brickGroup = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
+   HIP_CHECK(hipMemcpyAsync(sim->eam_pot.brickList, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice, st));
+   HIP_CHECK(hipMemcpyAsync(sim->eam_pot.brickGroup, group.data(), group.size() * sizeof(int), hipMemcpyHostToDevice, st));
+   HIP_CHECK(hipStreamSynchronize(st));                      // (the vectors go out of scope; the other stream of the overlap mode reads the lists too)
+   sim->eam_pot.brickCount[0] = cnt[0]; sim->eam_pot.brickCount[1] = cnt[1]; sim->eam_pot.brickCountAll = cnt[2]; sim->eam_pot.brickListStride = stride;
+   sim->eam_pot.brickGroupBy = b.by; sim->eam_pot.brickGroupBz = b.bz;
+}
+
 template <int STEP>
 static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* cells_list, hipStream_t st, int spline, bool listed, int method)
 {
@@ -848,7 +943,11 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
    { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
    const int group = eamBrickGroupOf(sim, cells_list, num_cells, method);
-   if (group) {            // the boundary / interior launch of the overlap mode: whole bricks (a brick with cells of both lists would be staged twice per pass)
+   if (listed) {           // the lists of the last list build (eamBrickBuildLists): all bricks, or the whole bricks of the boundary / interior launch
+      if (!sim->eam_pot.brickList) { fprintf(stderr, "eamForce: thread_atom_nl needs buildNeighborListGpu before the first force call\n"); exit(-1); }
+      b.brickList = sim->eam_pot.brickList + (size_t)(group ? group - 1 : 2) * sim->eam_pot.brickListStride;
+   }
+   if (group && !listed) {            // the boundary / interior launch of the overlap mode: whole bricks (a brick with cells of both lists would be staged twice per pass)
       if (!sim->eam_pot.brickGroup || sim->eam_pot.brickGroupBy != b.by || sim->eam_pot.brickGroupBz != b.bz) {
          if (!sim->eam_pot.brickGroup) sim->eam_pot.brickGroup = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
          if (!sim->eam_pot.cellSel) {
@@ -877,7 +976,7 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
       }
       // every cell of a listed brick is selected: no marks to look at (the embedding pass, a kernel over cells, uses brickGroup)
       b.brickList = sim->eam_pot.brickList + (group == 1 ? 0 : sim->eam_pot.brickListStride);
-   } else if (cells_list) {      // a launch over any other cell list: mark the cells, every brick looks at its own
+   } else if (cells_list && !group) {      // a launch over any other cell list: mark the cells, every brick looks at its own
       if (!sim->eam_pot.cellSel) {
          // zeroed ON THE LAUNCH STREAM: hipMemset returns before the device has finished, and the -a 1 streams are non-blocking -- a zeroing on
          // the null stream can land after the marks of the first launch (seen once in four-rank runs: a first force evaluation that skipped cells)
@@ -892,7 +991,7 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    if (listed && 3 * (b.by + 2) * (b.bz + 2) * 32 > EAM_BRICK_STAGE_LISTED * 64 * waves) { fprintf(stderr, "eamForce: a brick of 1 x %d x %d cells has more cells around it than a listed launch stages\n", b.by, b.bz); exit(-1); }
    const size_t lds = eamBrickLdsBytes(STEP, listed, tableDoubles, b.imageCap, b.rows, waves);
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
-   const int grid = group ? sim->eam_pot.brickCount[group - 1] : b.geom.g[0] * b.nby * b.nbz;
+   const int grid = group ? sim->eam_pot.brickCount[group - 1] : listed ? sim->eam_pot.brickCountAll : b.geom.g[0] * b.nby * b.nbz;
    if (grid <= 0) return;
 #define COMD_LAUNCH_EAM_BRICK(STP, TAB, SPL, LST) do { \
       allowDynamicLds((const void*)EAM_Force_cta_brick<STP, TAB, SPL, LST>, lds); \
@@ -1074,13 +1173,25 @@ extern "C" void advancePositionGpu(SimGpu* sim, real_t dt)
    LAUNCH_CHECK();
 }
 
+// Verlet lists: the fused drift kernels test the displacement since the list build as they write the new positions (step_kernels.h SkinCheck);
+// neighborListUpdateRequiredGpu then only reads the flag.  No lists, or none built yet: nothing to check.
+static SkinCheck skinCheckOf(SimGpu* sim)
+{
+   NeighborListGpu* n = &sim->atoms.neighborList;
+   SkinCheck sk = { nullptr, nullptr, nullptr, R(0.0), nullptr };
+   if (!n->lastR.x || n->nBuilds == 0 || n->forceRebuildFlag) return sk;
+   sk.lastX = n->lastR.x; sk.lastY = n->lastR.y; sk.lastZ = n->lastR.z; sk.skinHalf2 = n->skinDistanceHalf2; sk.flag = n->updateRequired;
+   n->checkFused = 1;
+   return sk;
+}
+
 extern "C" void advanceVelocityPositionGpu(SimGpu* sim, real_t dtKick, real_t dtDrift)
 {
    const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
    hipLaunchKernelGGL(AdvanceVelocityPosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
                       sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.iSpecies, sim->species_mass,
-                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick, dtDrift);
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick, dtDrift, skinCheckOf(sim));
    LAUNCH_CHECK();
 }
 
@@ -1090,7 +1201,7 @@ extern "C" void advanceVelocityVelocityPositionGpu(SimGpu* sim, real_t dtKick1, 
    hipLaunchKernelGGL(AdvanceVelocityVelocityPosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
                       sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.iSpecies, sim->species_mass,
-                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick1, dtKick2, dtDrift);
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick1, dtKick2, dtDrift, skinCheckOf(sim));
    LAUNCH_CHECK();
 }
 
@@ -1312,6 +1423,14 @@ extern "C" void unloadForceBufferToGpu2(const real_t* bufA, const real_t* bufB, 
                                         SimGpu* sim, comdStream_t stream)
 { unloadSlotBuffers(0, bufA, bufB, nCells, d_cellList, d_cellOffsets, sim, S(stream)); }
 
+extern "C" void mirrorSlotCellsGpu(int kind, int nPairs, const int* d_dst, const int* d_src, const real_t* d_shift, SimGpu* sim, comdStream_t stream)
+{
+   if (nPairs <= 0) return;
+   hipLaunchKernelGGL(MirrorSlotCells, dim3(nPairs), dim3(sortBlock(sim->maxAtoms)), 0, S(stream), kind, nPairs, d_dst, d_src, d_shift,
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->eam_pot.dfEmbed, sim->boxes.nAtoms, sim->maxAtoms);
+   LAUNCH_CHECK();
+}
+
 // ---- Verlet neighbour lists ------------------------------------------------------------------------------------------------
 extern "C" void emptyNeighborListGpu(SimGpu* sim, int)
 {
@@ -1326,12 +1445,23 @@ extern "C" int neighborListUpdateRequiredGpu(SimGpu* sim)
    NeighborListGpu* n = &sim->atoms.neighborList;
    if ((!n->list && !n->list16 && !n->pairlist && !n->brickRows) || n->forceRebuildFlag) return 1;
    hipStream_t st = S(sim->boundary_stream);
-   HIP_CHECK(hipMemsetAsync(n->updateRequired, 0, sizeof(int), st));
-   hipLaunchKernelGGL(NeighborListUpdateRequired, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
-                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, n->lastR.x, n->lastR.y, n->lastR.z,
-                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, n->skinDistanceHalf2, n->updateRequired);
-   LAUNCH_CHECK();
-   return comdReadDeviceInt(n->updateRequired, sim->boundary_stream);
+   // The flag lives in pinned host memory (the kernels write it there): a stream synchronisation and a host read, no copy.  It is raised only; the host
+   // clears it here, when nothing that writes it is in flight.
+   if (n->checkFused) {                                      // the drift kernel of the step checked the positions it wrote
+      n->checkFused = 0;
+      HIP_CHECK(hipStreamSynchronize(st));
+   } else {
+      HIP_CHECK(hipStreamSynchronize(st));
+      *n->updateRequiredHost = 0;
+      hipLaunchKernelGGL(NeighborListUpdateRequired, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
+                         sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, n->lastR.x, n->lastR.y, n->lastR.z,
+                         sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, n->skinDistanceHalf2, n->updateRequired);
+      LAUNCH_CHECK();
+      HIP_CHECK(hipStreamSynchronize(st));
+   }
+   const int v = *(volatile int*)n->updateRequiredHost;
+   *n->updateRequiredHost = 0;
+   return v;
 }
 
 extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
@@ -1354,7 +1484,7 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
    if (n->slabFormat == 4) {
       // rows of the brick kernel: the cells were just re-binned, so the image is sized again for the fullest block; STEP 0 sweeps every brick once
       hipStream_t st = S(sim->boundary_stream);
-      sim->eam_pot.brickImageCap = 0;
+      eamBrickBuildLists(sim, st, sim->eam_pot.phiS.coefficients != nullptr);      // (sizes the image as well)
       EamArgs a = makeEamArgs(sim, sim->boxes.nLocalBoxes, nullptr);
       if (!sim->eam_pot.brickStats) sim->eam_pot.brickStats = dalloc<int>(2);
       HIP_CHECK(hipMemsetAsync(sim->eam_pot.brickStats, 0, 2 * sizeof(int), st));

@@ -131,9 +131,13 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
 
    // ---- the brick and its selected cells -------------------------------------------------------------------------------------------
    const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2];
-   const int bid = b.brickList ? b.brickList[xcdRemap(blockIdx.x, gridDim.x)] : xcdRemap(blockIdx.x, gridDim.x);      // x fastest: consecutive bricks share two thirds of their block
-   const int bx = bid % gx, by0 = ((bid / gx) % b.nby) * b.by, bz0 = (bid / (gx * b.nby)) * b.bz;
-   const int HY = b.by + 2, HZ = b.bz + 2, NH = 3 * HY * HZ, NC = b.by * b.bz;
+   const int entry = b.brickList ? b.brickList[xcdRemap(blockIdx.x, gridDim.x)] : xcdRemap(blockIdx.x, gridDim.x);      // x fastest: consecutive bricks share two thirds of their block
+   // Listed launches take their bricks from a list the host makes at every list build, when the occupancies are known and frozen: a brick whose block would
+   // outgrow the image is listed as its two z halves (bits 28-29: 1 lower, 2 upper half), each staged and numbered on its own -- in every pass until the next build.
+   const int half = LISTED ? (entry >> 28) & 3 : 0, bid = LISTED ? entry & 0x0fffffff : entry;
+   const int bzN = half ? b.bz >> 1 : b.bz;                  // cells of this (half) brick along z
+   const int bx = bid % gx, by0 = ((bid / gx) % b.nby) * b.by, bz0 = (bid / (gx * b.nby)) * b.bz + (half == 2 ? b.bz >> 1 : 0);
+   const int HY = b.by + 2, HZ = bzN + 2, NH = 3 * HY * HZ, NC = b.by * bzN;
    unsigned long long selMask;
    if (b.sel) {      // a launch over a cell list: one more round trip, for the marks of the brick's cells
       if (wave == 0) {
@@ -186,7 +190,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
    // A brick away from the faces of the local grid with every cell selected -- nearly all of them -- has a block of local cells, numbered
    // x + gx (y + gy z), all of them needed.
    const bool plain = !b.geom.lookup && selMask == (NC >= 64 ? ~0ull : (1ull << NC) - 1ull) && bx >= 1 && bx <= gx - 2 && by0 >= 1 && by0 + b.by <= gy - 1
-                      && bz0 >= 1 && bz0 + b.bz <= gz - 1;
+                      && bz0 >= 1 && bz0 + bzN <= gz - 1;
    if (plain) {
       const int hyMagic = (65536 + HY - 1) / HY;             // t / HY = (t * hyMagic) >> 16 for t < 128
       const int base = (bx - 1) + gx * ((by0 - 1) + gy * (bz0 - 1)), gxy = gx * gy;
@@ -215,7 +219,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
 #pragma unroll
                      for (int dy = -1; dy <= 1; ++dy) {
                         const int cy = yh - 1 + dy, cz = zh - 1 + dz;
-                        if (cy >= 0 && cy < b.by && cz >= 0 && cz < b.bz) need = need || ((selMask >> (cy + b.by * cz)) & 1ull);
+                        if (cy >= 0 && cy < b.by && cz >= 0 && cz < bzN) need = need || ((selMask >> (cy + b.by * cz)) & 1ull);
                      }
                }
                if (need) box = comdBoxFromTuple(&b.geom, bx + xh - 1, iy, iz);

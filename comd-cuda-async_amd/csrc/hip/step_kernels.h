@@ -37,13 +37,23 @@ void AdvancePosition(real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* _
    rx[tid] += dt * px[tid] * invMass; ry[tid] += dt * py[tid] * invMass; rz[tid] += dt * pz[tid] * invMass;
 }
 
+// [round 4] Verlet lists: the drift kernels also answer "has an atom moved more than skin/2 since the list build?" (gpu_kernels.cu:1087-1110) for the
+// positions they have just written -- the separate pass over r and lastR (40 us at EAM 80^3) is gone.  lastX == NULL: no lists, nothing is checked.
+struct SkinCheck { const real_t* lastX; const real_t* lastY; const real_t* lastZ; real_t skinHalf2; int* flag; };
+__device__ __forceinline__ void skinCheck(const SkinCheck& sk, long s, real_t x, real_t y, real_t z)
+{
+   if (!sk.lastX) return;
+   const real_t dx = x - sk.lastX[s], dy = y - sk.lastY[s], dz = z - sk.lastZ[s];
+   if (dx*dx + dy*dy + dz*dz > sk.skinHalf2) *sk.flag = 1;
+}
+
 // half kick followed by the drift in one pass (same operations, same order, as AdvanceVelocity then AdvancePosition)
 __global__ __launch_bounds__(256)
 void AdvanceVelocityPosition(real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* __restrict__ rz,
                              real_t* __restrict__ px, real_t* __restrict__ py, real_t* __restrict__ pz,
                              const real_t* __restrict__ fx, const real_t* __restrict__ fy, const real_t* __restrict__ fz,
                              const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
-                             const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick, real_t dtDrift)
+                             const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick, real_t dtDrift, SkinCheck sk)
 {
    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(tid / cap);
@@ -51,7 +61,9 @@ void AdvanceVelocityPosition(real_t* __restrict__ rx, real_t* __restrict__ ry, r
    const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];
    const real_t x = px[tid] + dtKick * fx[tid], y = py[tid] + dtKick * fy[tid], z = pz[tid] + dtKick * fz[tid];
    px[tid] = x; py[tid] = y; pz[tid] = z;
-   rx[tid] += dtDrift * x * invMass; ry[tid] += dtDrift * y * invMass; rz[tid] += dtDrift * z * invMass;
+   const real_t nx = rx[tid] + dtDrift * x * invMass, ny = ry[tid] + dtDrift * y * invMass, nz = rz[tid] + dtDrift * z * invMass;
+   rx[tid] = nx; ry[tid] = ny; rz[tid] = nz;
+   skinCheck(sk, tid, nx, ny, nz);
 }
 
 // second half kick of one step + first half kick and drift of the next, one pass (same operations, same order, as AdvanceVelocity followed
@@ -61,7 +73,7 @@ void AdvanceVelocityVelocityPosition(real_t* __restrict__ rx, real_t* __restrict
                                      real_t* __restrict__ px, real_t* __restrict__ py, real_t* __restrict__ pz,
                                      const real_t* __restrict__ fx, const real_t* __restrict__ fy, const real_t* __restrict__ fz,
                                      const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
-                                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick1, real_t dtKick2, real_t dtDrift)
+                                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick1, real_t dtKick2, real_t dtDrift, SkinCheck sk)
 {
    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(tid / cap);
@@ -71,7 +83,9 @@ void AdvanceVelocityVelocityPosition(real_t* __restrict__ rx, real_t* __restrict
    real_t x = px[tid] + dtKick1 * gx, y = py[tid] + dtKick1 * gy, z = pz[tid] + dtKick1 * gz;
    x += dtKick2 * gx; y += dtKick2 * gy; z += dtKick2 * gz;
    px[tid] = x; py[tid] = y; pz[tid] = z;
-   rx[tid] += dtDrift * x * invMass; ry[tid] += dtDrift * y * invMass; rz[tid] += dtDrift * z * invMass;
+   const real_t nx = rx[tid] + dtDrift * x * invMass, ny = ry[tid] + dtDrift * y * invMass, nz = rz[tid] + dtDrift * z * invMass;
+   rx[tid] = nx; ry[tid] = ny; rz[tid] = nz;
+   skinCheck(sk, tid, nx, ny, nz);
 }
 
 // ---- energy: stage 1 = per-block partial sums in a fixed order, stage 2 = one block adds the partials --------
@@ -425,4 +439,23 @@ void UnloadPositionBuffer(SlotJob j0, SlotJob j1, real_t* __restrict__ rx, real_
       const real_t* o = jb.buf + 3 * (size_t)(jb.offsets[blockIdx.x] + threadIdx.x);
       rx[s] = o[0]; ry[s] = o[1]; rz[s] = o[2];
    }
+}
+
+// ---- [round 4] self-neighbour axes: halo cells filled straight from the cells they are periodic images of ------------------------------------------
+// On an axis where a rank is its own minus and plus neighbour the destination of every halo cell is known: dst[k] is the image of src[k], displaced by
+// shift[3k..3k+2].  The host resolves the x -> y -> z ordering of the exchange (haloExchange.c:1504-1520: an edge or corner cell is the image of an image)
+// into ONE source per halo cell -- each coordinate is shifted by at most one axis, so the sum of the shifts is the same arithmetic as the chain -- and one
+// launch takes the place of pack + unpack per axis.  Positional, like the messages it replaces: slot i of dst = slot i of src.  blockDim.x >= cap.
+__global__
+void MirrorSlotCells(int kind, int nPairs, const int* __restrict__ dst, const int* __restrict__ src, const real_t* __restrict__ shift,
+                     real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* __restrict__ rz, real_t* __restrict__ dfEmbed,
+                     const int* __restrict__ nAtoms, int cap)
+{
+   const int k = blockIdx.x;
+   if (k >= nPairs) return;
+   const int d = dst[k], c = src[k];
+   if ((int)threadIdx.x >= nAtoms[d]) return;
+   const size_t to = (size_t)d * cap + threadIdx.x, from = (size_t)c * cap + threadIdx.x;
+   if (kind == 0) dfEmbed[to] = dfEmbed[from];
+   else { rx[to] = rx[from] + shift[3 * k]; ry[to] = ry[from] + shift[3 * k + 1]; rz[to] = rz[from] + shift[3 * k + 2]; }
 }

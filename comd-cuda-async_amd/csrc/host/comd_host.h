@@ -203,6 +203,9 @@ typedef struct HaloExchangeSt {
    /* optional: tell the plugin the agreed sizes (atoms) of the message it packs for `face` and of the one it unpacks for `face`; 0 = none */
    void (*setBounds)(void* parms, int face, int sendBoundAtoms, int recvBoundAtoms);
    HaloSpec spec[3];
+   /* optional: fill the halo cells of axes firstAxis..2 (all of them self-neighbour axes) straight from their sources, one launch (comd_hip.h mirrorSlotCellsGpu) */
+   void (*mirror)(struct HaloExchangeSt* hh, void* data, int firstAxis);
+   int nTotalBoxes;                       /* (for the mirror map) */
 } HaloExchange;
 
 typedef struct AtomExchangeParmsSt {
@@ -224,6 +227,9 @@ typedef struct ForceExchangeParmsSt {
    int* d_cellOffsets;
    int capacityAtoms;
    int positions;                         /* 0: dF/drho (1 real per atom); 1: positions + face shift (3 reals per atom) */
+   /* mirror map of the self-neighbour tail firstAxis..2 (built on first use): halo cell mirrorDst[k] is the image of mirrorSrc[k] displaced by mirrorShift[3k..] */
+   int mirrorFirst, mirrorPairs;
+   int *mirrorDstGpu, *mirrorSrcGpu; real_t* mirrorShiftGpu;
    real_t shift[6][3];
    int msgBytesCached[6];                 /* positions: message sizes are fixed between list builds; -1 = unknown */
    int sendBound[6];                      /* agreed message sizes in atoms, 0 = none */
@@ -237,6 +243,7 @@ void preparePositionExchange(HaloExchange* positionExchange, struct SimFlatSt* s
 void destroyHaloExchange(HaloExchange** haloExchange);
 void invalidateHaloSizes(HaloExchange* haloExchange);      /* the next exchange of every axis swaps exact sizes again */
 void haloExchange(HaloExchange* haloExchange, void* data);
+int  haloMirrorFirstAxis(const HaloExchange* hh);         /* first axis of the self-neighbour tail the plugin mirrors directly; 3 = none */
 void exchangeData(HaloExchange* haloExchange, void* data, int iAxis);
 void prepareForceExchange(HaloExchange* forceExchange, struct SimFlatSt* sim);   /* one batched scan of all twelve cell lists */
 int* mkAtomCellList(LinkCell* boxes, enum HaloFaceOrder iFace, int nCells);

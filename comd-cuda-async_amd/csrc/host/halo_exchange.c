@@ -305,6 +305,58 @@ static void destroyForceExchange(void* vparms)
    comdDeviceFree(parms->d_cellOffsets);
 }
 
+/* [round 4] Self-neighbour axes at the END of the x -> y -> z sequence (all three on one rank; y and z on a 2 x 1 x 1 grid; z on 2 x 2 x 1): every halo
+ * cell they fill is the periodic image of one known cell.  What a rank sends through face F arrives at its own opposite face (haloExchange.c:788-853), and a
+ * later axis re-sends the halo cells of the earlier ones (:1504-1520), so an edge or corner cell is the image of an image: the chain is folded here, once,
+ * into (halo cell, source cell, total shift) triples -- a coordinate is shifted by at most one axis of the chain, so adding the total is the same arithmetic --
+ * and ONE launch (comd_hip.h mirrorSlotCellsGpu) replaces a pack and an unpack per axis.  COMD_HALO_MIRROR=0 keeps the message path (A/B runs). */
+int haloMirrorFirstAxis(const HaloExchange* hh)
+{
+   static int enabled = -1;
+   if (enabled < 0) { const char* e = getenv("COMD_HALO_MIRROR"); enabled = !(e && atoi(e) == 0); }
+   if (!enabled || !hh->mirror || !hh->deviceBuffers || loopbackParallel()) return 3;
+   int first = 3;
+   for (int a = 2; a >= 0; --a) {
+      if (hh->nbrRank[2 * a] == getMyRank() && hh->nbrRank[2 * a + 1] == getMyRank()) first = a; else break;
+   }
+   return first;
+}
+
+static void slotMirror(HaloExchange* hh, void* vdata, int firstAxis)
+{
+   ForceExchangeParms* parms = (ForceExchangeParms*)hh->parms;
+   SimFlat* s = (SimFlat*)vdata;
+   if (!parms->mirrorDstGpu || parms->mirrorFirst != firstAxis) {
+      int n = 0;
+      for (int a = firstAxis; a < 3; ++a) n += 2 * parms->nCells[2 * a];
+      int* dst = (int*)malloc((size_t)n * sizeof(int)); int* src = (int*)malloc((size_t)n * sizeof(int));
+      real_t* sh = (real_t*)calloc((size_t)3 * n, sizeof(real_t));
+      int* rootOf = (int*)malloc((size_t)hh->nTotalBoxes * sizeof(int));
+      real_t* shiftOf = (real_t*)calloc((size_t)3 * hh->nTotalBoxes, sizeof(real_t));
+      for (int c = 0; c < hh->nTotalBoxes; ++c) rootOf[c] = -1;
+      int k = 0;
+      for (int a = firstAxis; a < 3; ++a)
+         for (int dir = 0; dir < 2; ++dir) {
+            const int faceSend = 2 * a + dir, faceRecv = 2 * a + (1 - dir);     /* what leaves through a face arrives at the opposite one */
+            for (int i = 0; i < parms->nCells[faceSend]; ++i, ++k) {
+               int from = parms->sendCells[faceSend][i];
+               const int to = parms->recvCells[faceRecv][i];
+               real_t t[3] = { parms->shift[faceSend][0], parms->shift[faceSend][1], parms->shift[faceSend][2] };
+               if (rootOf[from] >= 0) { for (int d = 0; d < 3; ++d) t[d] += shiftOf[3 * from + d]; from = rootOf[from]; }      /* a halo cell of an earlier axis of the chain */
+               rootOf[to] = from; for (int d = 0; d < 3; ++d) shiftOf[3 * to + d] = t[d];
+               dst[k] = to; src[k] = from; for (int d = 0; d < 3; ++d) sh[3 * k + d] = t[d];
+            }
+         }
+      if (parms->mirrorDstGpu) { comdDeviceFree(parms->mirrorDstGpu); comdDeviceFree(parms->mirrorSrcGpu); comdDeviceFree(parms->mirrorShiftGpu); }
+      parms->mirrorDstGpu = uploadInts(dst, n); parms->mirrorSrcGpu = uploadInts(src, n);
+      parms->mirrorShiftGpu = (real_t*)comdDeviceMalloc((long)3 * n * sizeof(real_t));
+      comdMemcpyHtoD(parms->mirrorShiftGpu, sh, (long)3 * n * sizeof(real_t));
+      parms->mirrorFirst = firstAxis; parms->mirrorPairs = n;
+      free(dst); free(src); free(sh); free(rootOf); free(shiftOf);
+   }
+   mirrorSlotCellsGpu(parms->positions ? 1 : 0, parms->mirrorPairs, parms->mirrorDstGpu, parms->mirrorSrcGpu, parms->mirrorShiftGpu, &s->gpu, s->gpu.boundary_stream);
+}
+
 HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice)
 {
    HaloExchange* hh = initHaloExchangeBase(domain);
@@ -329,6 +381,7 @@ HaloExchange* initForceHaloExchange(Domain* domain, LinkCell* boxes, int allocDe
    hh->type = 1;
    hh->parms = parms;
    hh->deviceBuffers = allocDevice;
+   hh->nTotalBoxes = boxes->nTotalBoxes; if (allocDevice) hh->mirror = slotMirror;
    hh->msgHeaderBytes = 0; hh->msgBytesPerAtom = (int)sizeof(real_t); hh->capacityAtoms = parms->capacityAtoms;
    hh->countPtrs = forceCountPtrs; hh->setBounds = forceSetBounds;
    if (allocDevice) { hh->loadBuffer2 = loadSlotBuffer2; hh->unloadBuffer2 = unloadSlotBuffer2; }
@@ -413,6 +466,7 @@ HaloExchange* initPositionHaloExchange(Domain* domain, LinkCell* boxes, int allo
    hh->type = 2;
    hh->parms = parms;
    hh->deviceBuffers = allocDevice;
+   hh->nTotalBoxes = boxes->nTotalBoxes; if (allocDevice) hh->mirror = slotMirror;
    hh->msgHeaderBytes = 0; hh->msgBytesPerAtom = 3 * (int)sizeof(real_t); hh->capacityAtoms = parms->capacityAtoms;
    hh->countPtrs = forceCountPtrs; hh->setBounds = forceSetBounds;
    if (allocDevice) { hh->loadBuffer2 = loadSlotBuffer2; hh->unloadBuffer2 = unloadSlotBuffer2; }
@@ -461,6 +515,7 @@ void destroyHaloExchange(HaloExchange** pp)
 void prepareForceExchange(HaloExchange* hh, SimFlat* sim)
 {
    ForceExchangeParms* parms = (ForceExchangeParms*)hh->parms;
+   if (haloMirrorFirstAxis(hh) == 0) return;                 /* no message is packed: no offsets needed */
    int* lists[12]; int* offs[12]; int n[12];
    for (int f = 0; f < 6; ++f) {
       lists[f] = parms->sendCellsGpu[f];     offs[f] = parms->sendOffsetsGpu[f];     n[f] = parms->nCells[f];
@@ -605,6 +660,8 @@ void exchangeData(HaloExchange* hh, void* data, int iAxis)
 void haloExchange(HaloExchange* hh, void* data)
 {
    startTimer(commHaloTimer);
-   for (int iAxis = 0; iAxis < 3; ++iAxis) exchangeData(hh, data, iAxis);
+   const int first = haloMirrorFirstAxis(hh);               /* axes first..2: this rank is its own neighbour and the plugin can mirror cells directly */
+   for (int iAxis = 0; iAxis < first; ++iAxis) exchangeData(hh, data, iAxis);
+   if (first < 3) hh->mirror(hh, data, first);
    stopTimer(commHaloTimer);
 }

@@ -92,6 +92,8 @@ typedef struct EamPotentialGpu {
    int     brickGroupBy, brickGroupBz; /* the brick shape the groups were built for */
    int*    brickList;                  /* device [2][brickListStride]: the bricks of group 1, of group 2 (what a group launch's workgroups take) */
    int     brickCount[2], brickListStride;
+   int     brickCountAll;              /* Verlet rows (slabFormat 4): the lists are made by every list build -- [0] boundary bricks, [1] the others, [2 * stride ..) all; an entry is a
+                                        * brick number, or with bits 28-29 set the lower (1) / upper (2) z half of a brick whose block would outgrow the LDS image */
    int*    cellSel;                    /* device [nLocalBoxes] */
    int     selTag;                     /* host: tag of the last list launch */
    /* [round 4] per cell, the selection (64-bit mask of the brick's cells) its brick was staged for when pass 1 wrote the cell's rows; pass 3 of the same force evaluation must be launched over
@@ -119,7 +121,9 @@ typedef struct NeighborListGpu {
    int*   nNeighbors;                  /* device [nLocalBoxes * maxAtoms] */
    int    maxNeighbors;                /* rows per cell (gpu_neighborList.c:50 MAXNEIGHBORLISTSIZE) */
    vec_t  lastR;                       /* device [nLocalBoxes * maxAtoms]: positions at the last build */
-   int*   updateRequired;              /* device [1] */
+   int*   updateRequired;              /* device view of updateRequiredHost */
+   int*   updateRequiredHost;          /* pinned host [1]: raised by the displacement test (the fused drift kernels or NeighborListUpdateRequired), cleared by the host */
+   int    checkFused;                  /* host: a fused drift kernel has tested the positions it wrote since the last neighborListUpdateRequiredGpu */
    real_t skinDistance, skinDistance2, skinDistanceHalf2;
    /* LJ (cells of <= 512 slots): the list is kept per group of stencil cells (the 3 x-planes of 9 cells) as 16-bit indices into the
     * LDS staging of that group: list16[((c*3 + g)*slabRows + k)*maxAtoms + i], nNeighbors[(c*3 + g)*maxAtoms + i]; `list` is unused */
@@ -470,6 +474,11 @@ void loadPositionBufferFromGpu2(real_t* bufM, real_t* bufP, const int nCells[2],
                                 const int boundAtoms[2], const real_t shiftM[3], const real_t shiftP[3], SimGpu* sim, comdStream_t stream);
 void unloadPositionBufferToGpu2(const real_t* bufA, const real_t* bufB, const int nCells[2], int* const d_cellList[2], int* const d_cellOffsets[2],
                                 SimGpu* sim, comdStream_t stream);
+
+/* [round 4] Axes on which a rank is its own neighbour (all three on one rank): the halo cells are filled straight from the cells they are images of, one
+ * launch for every such axis at the end of the x -> y -> z sequence instead of a pack and an unpack per axis (same values: haloExchange.c:788-853 is the
+ * reference's self-neighbour branch, :1504-1520 the ordering the host folds into one source per halo cell).  kind 0: dfEmbed, 1: positions + d_shift[3k..]. */
+void mirrorSlotCellsGpu(int kind, int nPairs, const int* d_dst, const int* d_src, const real_t* d_shift, SimGpu* sim, comdStream_t stream);
 
 /* ---- device-side timing for bench.py -------------------------------------------------------- */
 /* HIP-event pair on a stream: comdEventCreate/Record/ElapsedMs.  Used to time kernels on the stream they
