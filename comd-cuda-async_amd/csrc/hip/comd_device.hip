@@ -335,6 +335,8 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
    }
    sim->nAtomsPrev = dalloc<int>(cfg->nTotalBoxes);
    sim->cellDirty = dalloc<int>(cfg->nTotalBoxes);
+   sim->cellArrivals = dalloc<int>((size_t)3 * cfg->nTotalBoxes);
+   sim->d_updateLinkCellsRequired = dalloc<int>(1);
    sim->status = dalloc<int>(4);
    sim->reduceBlocks = 1024;
    sim->reduceBuf = dalloc<real_t>(2 * (size_t)sim->reduceBlocks + 2);
@@ -402,6 +404,56 @@ extern "C" void updateNAtomsCpu(SimGpu* sim, int* nAtomsHost)
    sim->max_atoms_cell = m;                       // gpu_types.h:160 max_atoms_cell: sizes the LJ thread_atom workgroups
 }
 
+// gpu_utility.h:60-69, the rest of the staging surface (the reference's cpu_nl path moves atoms between its host arrays and the device with these)
+extern "C" void cudaCopyDtH(void* dst, const void* src, int size) { HIP_CHECK(hipMemcpy(dst, src, (size_t)size, hipMemcpyDeviceToHost)); }      // gpu_utility.c:46-49, same signature
+
+extern "C" void GetLocalAtomsFromGpu(SimGpu* sim, HostAtoms* h)                     // gpu_utility.c:656-673: momenta, positions and gids of the LOCAL cells
+{
+   HIP_CHECK(hipDeviceSynchronize());
+   const size_t slots = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
+   real_t* dst[6] = { h->px, h->py, h->pz, h->rx, h->ry, h->rz };
+   real_t* src[6] = { sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z, sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z };
+   for (int i = 0; i < 6; ++i) if (dst[i]) HIP_CHECK(hipMemcpy(dst[i], src[i], slots * sizeof(real_t), hipMemcpyDeviceToHost));
+   if (h->gid) HIP_CHECK(hipMemcpy(h->gid, sim->atoms.gid, slots * sizeof(int), hipMemcpyDeviceToHost));
+}
+
+extern "C" void updateGpuHalo(SimGpu* sim, const HostAtoms* h)                       // gpu_utility.c:714-757: the HALO cells' slots, host -> device
+{
+   const size_t first = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms, slots = (size_t)(sim->boxes.nTotalBoxes - sim->boxes.nLocalBoxes) * sim->maxAtoms;
+   const real_t* src[6] = { h->px, h->py, h->pz, h->rx, h->ry, h->rz };
+   real_t* dst[6] = { sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z, sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z };
+   for (int i = 0; i < 6; ++i) HIP_CHECK(hipMemcpy(dst[i] + first, src[i] + first, slots * sizeof(real_t), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.gid + first, h->gid + first, slots * sizeof(int), hipMemcpyHostToDevice));
+   HIP_CHECK(hipMemcpy(sim->atoms.iSpecies + first, h->iSpecies + first, slots * sizeof(int), hipMemcpyHostToDevice));
+}
+
+extern "C" void updateNAtomsGpu(SimGpu* sim, const int* nAtomsHost)                  // gpu_utility.c:602-605
+{
+   HIP_CHECK(hipMemcpy(sim->boxes.nAtoms, nAtomsHost, (size_t)sim->boxes.nTotalBoxes * sizeof(int), hipMemcpyHostToDevice));
+}
+
+// gpu_utility.c:678-712, a host loop there as here: the atoms of the halo cells, cell by cell, as one SoA message in h_compactAtoms (no header);
+// h_cellOffset[i] = atoms in the halo cells before the i-th, nHalo + 1 entries.  (The reference zeroes h_cellOffset[nLocalBoxes] instead of [0] and
+// relies on the caller's calloc; entry 0 is written here.)
+extern "C" int compactHaloCells(const HostAtoms* h, int nLocalBoxes, int nTotalBoxes, int maxAtoms, char* h_compactAtoms, int* h_cellOffset)
+{
+   const int nHalo = nTotalBoxes - nLocalBoxes;
+   h_cellOffset[0] = 0;
+   for (int i = 0; i < nHalo; ++i) h_cellOffset[i + 1] = h_cellOffset[i] + h->nAtoms[nLocalBoxes + i];
+   const int n = h_cellOffset[nHalo];
+   int* gid = (int*)h_compactAtoms; int* type = gid + n;
+   real_t* m = (real_t*)(type + n);
+   for (int i = 0; i < nHalo; ++i) {
+      size_t o = (size_t)(nLocalBoxes + i) * maxAtoms;
+      for (int k = h_cellOffset[i]; k < h_cellOffset[i + 1]; ++k, ++o) {
+         gid[k] = h->gid[o]; type[k] = h->iSpecies[o];
+         m[k] = h->rx[o]; m[(size_t)n + k] = h->ry[o]; m[2 * (size_t)n + k] = h->rz[o];
+         m[3 * (size_t)n + k] = h->px[o]; m[4 * (size_t)n + k] = h->py[o]; m[5 * (size_t)n + k] = h->pz[o];
+      }
+   }
+   return n;
+}
+
 extern "C" void DestroyGpu(SimGpu* sim)
 {
    HIP_CHECK(hipDeviceSynchronize());
@@ -414,7 +466,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
    void* ptrs[] = { sim->boxes.nAtoms, sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
                     sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.e, sim->atoms.iSpecies, sim->atoms.gid,
                     sim->neighbor_cells, sim->species_mass, sim->eam_pot.phi.values, sim->eam_pot.rho.values, sim->eam_pot.f.values,
-                    sim->eam_pot.rhobar, sim->eam_pot.dfEmbed, sim->nAtomsPrev, sim->cellDirty, sim->status, sim->reduceBuf,
+                    sim->eam_pot.rhobar, sim->eam_pot.dfEmbed, sim->nAtomsPrev, sim->cellDirty, sim->cellArrivals, sim->d_updateLinkCellsRequired, sim->status, sim->reduceBuf,
                     sim->boundary_cells, sim->interior_cells, sim->boundary1_cells,
                     sim->atoms.neighborList.list, sim->atoms.neighborList.nNeighbors, sim->atoms.neighborList.lastR.x,
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z,
@@ -1241,13 +1293,13 @@ static void launchCompactSort(SimGpu* sim, int first, int nCells, hipStream_t st
    if (sim->maxAtoms <= 64) {
       const int run = halo ? 2 : COMPACT_RUN_WAVE;
       hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4 * run)), dim3(256), 0, st,
-                         atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, first, nCells, sim->maxAtoms, run);
+                         atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, first, nCells, sim->maxAtoms, run, sim->cellArrivals, sim->boxes.nTotalBoxes);
       LAUNCH_CHECK();
       return;
    }
    const int run = halo ? 1 : COMPACT_RUN;
    hipLaunchKernelGGL(CompactSortCells, dim3(ceilDiv(nCells, run)), dim3(sortBlock(sim->maxAtoms)), (size_t)sortBlock(sim->maxAtoms) * sizeof(int), st,
-                      atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, first, nCells, sim->maxAtoms, run);
+                      atomArrays(sim), sim->boxes.nAtoms, sim->cellDirty, sim->status, first, nCells, sim->maxAtoms, run, sim->cellArrivals, sim->boxes.nTotalBoxes);
    LAUNCH_CHECK();
 }
 
@@ -1255,7 +1307,7 @@ extern "C" void updateLinkCellsGpu(SimGpu* sim, comdStream_t stream)
 {
    hipStream_t st = S(stream);
    const int nLocal = sim->boxes.nLocalBoxes, nTotal = sim->boxes.nTotalBoxes;
-   hipLaunchKernelGGL(SnapshotCells, dim3(ceilDiv(nTotal, 256)), dim3(256), 0, st, sim->boxes.nAtoms, sim->nAtomsPrev, sim->cellDirty, nLocal, nTotal);
+   hipLaunchKernelGGL(SnapshotCells, dim3(ceilDiv(nTotal, 256)), dim3(256), 0, st, sim->boxes.nAtoms, sim->nAtomsPrev, sim->cellDirty, sim->cellArrivals, nLocal, nTotal);
    hipLaunchKernelGGL(UpdateLinkCells, dim3(ceilDiv((long)nLocal * sim->maxAtoms, 256)), dim3(256), 0, st,
                       atomArrays(sim), sim->boxes.nAtoms, sim->nAtomsPrev, sim->cellDirty, sim->status, sim->boxes, sim->maxAtoms);
    LAUNCH_CHECK();
@@ -1423,6 +1475,21 @@ extern "C" void unloadForceBufferToGpu2(const real_t* bufA, const real_t* bufB, 
                                         SimGpu* sim, comdStream_t stream)
 { unloadSlotBuffers(0, bufA, bufB, nCells, d_cellList, d_cellOffsets, sim, S(stream)); }
 
+extern "C" void mirrorAtomCellsGpu(const int nCells[2], int* const d_cellList[2], const real_t shiftM[3], const real_t shiftP[3], int firstAxis, int axis,
+                                   SimGpu* sim, comdStream_t stream)
+{
+   MirrorAtomsJob jb;
+   for (int f = 0; f < 2; ++f) {
+      const real_t* sh = f ? shiftP : shiftM;
+      jb.list[f] = d_cellList[f]; jb.nCells[f] = nCells[f]; jb.sx[f] = sh[0]; jb.sy[f] = sh[1]; jb.sz[f] = sh[2];
+   }
+   const int most = maxInt(nCells[0], nCells[1]);
+   if (most <= 0) return;
+   hipLaunchKernelGGL(MirrorAtomCells, dim3(ceilDiv((long)most * sim->maxAtoms, 256), 2), dim3(256), 0, S(stream), jb, atomArrays(sim), sim->boxes.nAtoms,
+                      sim->cellArrivals, sim->boxes.nTotalBoxes, firstAxis, axis, sim->cellDirty, sim->status, sim->boxes, sim->maxAtoms);
+   LAUNCH_CHECK();
+}
+
 extern "C" void mirrorSlotCellsGpu(int kind, int nPairs, const int* d_dst, const int* d_src, const real_t* d_shift, SimGpu* sim, comdStream_t stream)
 {
    if (nPairs <= 0) return;
@@ -1438,7 +1505,7 @@ extern "C" void emptyNeighborListGpu(SimGpu* sim, int)
    if (n->nNeighbors) HIP_CHECK(hipMemsetAsync(n->nNeighbors, 0, (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * (n->slabFormat == 1 ? NL_GROUPS : 1) * sizeof(int), S(sim->boundary_stream)));
 }
 
-extern "C" void neighborListForceRebuildGpu(SimGpu* sim) { sim->atoms.neighborList.forceRebuildFlag = 1; }
+extern "C" void neighborListForceRebuildGpu(NeighborListGpu* nl) { nl->forceRebuildFlag = 1; }      // gpu_neighborList.c:88-93, same signature
 
 extern "C" int neighborListUpdateRequiredGpu(SimGpu* sim)
 {

@@ -131,12 +131,13 @@ void ReduceEnergyFinal(const real_t* __restrict__ partial, int nPartial, real_t*
 // ---- redistribution -------------------------------------------------------------------------------------
 // snapshot local occupancies, empty the halo cells (timestep.c:224), clear dirty flags
 __global__ __launch_bounds__(256)
-void SnapshotCells(int* __restrict__ nAtoms, int* __restrict__ nAtomsPrev, int* __restrict__ dirty, int nLocal, int nTotal)
+void SnapshotCells(int* __restrict__ nAtoms, int* __restrict__ nAtomsPrev, int* __restrict__ dirty, int* __restrict__ arrivals, int nLocal, int nTotal)
 {
    const int c = blockIdx.x * blockDim.x + threadIdx.x;
    if (c >= nTotal) return;
    if (c < nLocal) nAtomsPrev[c] = nAtoms[c]; else { nAtoms[c] = 0; nAtomsPrev[c] = 0; }
    dirty[c] = 0;
+   arrivals[c] = 0; arrivals[nTotal + c] = 0; arrivals[2 * (size_t)nTotal + c] = 0;      // (MirrorAtomCells below)
 }
 
 struct AtomArrays {
@@ -175,7 +176,7 @@ void UpdateLinkCells(AtomArrays at, int* __restrict__ nAtoms, const int* __restr
 #define COMPACT_RUN 8
 __global__
 void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int* __restrict__ status,
-                      int first, int nCells, int cap, int run)
+                      int first, int nCells, int cap, int run, int* __restrict__ arrivals, int nTotal)
 {
    extern __shared__ int sKey[];
    __shared__ int sFlag[COMPACT_RUN];
@@ -189,7 +190,7 @@ void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__
       if (idx >= nCells) return;
       const int c = first + idx;
       if (!sFlag[k]) continue;                              // workgroup-uniform
-      int n = nAtoms[c];
+      int n = nAtoms[c] + arrivals[c] + arrivals[nTotal + c] + arrivals[2 * (size_t)nTotal + c];      // (atoms mirrored in on self-neighbour axes are counted beside the cell)
       if (n > cap) n = cap;                                  // overflow already flagged by the writer
       const size_t o = (size_t)c * cap + t;
       int key = 0x7fffffff, spec = 0;
@@ -208,14 +209,15 @@ void CompactSortCells(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__
          at.gid[d] = key; at.spec[d] = spec;
          at.rx[d] = x; at.ry[d] = y; at.rz[d] = z; at.px[d] = px; at.py[d] = py; at.pz[d] = pz;
       }
-      if (t == 0) { nAtoms[c] = live; dirty[c] = 0; }
+      if (t == 0) { nAtoms[c] = live; dirty[c] = 0; arrivals[c] = 0; arrivals[nTotal + c] = 0; arrivals[2 * (size_t)nTotal + c] = 0; }
    }
 }
 
 // Same for cap <= 64: one WAVE per run of COMPACT_RUN_WAVE cells, four waves per workgroup, keys exchanged with v_readlane (no LDS, no barrier).
 #define COMPACT_RUN_WAVE 16
 __global__ __launch_bounds__(256)
-void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int first, int nCells, int cap, int run)
+void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restrict__ dirty, int first, int nCells, int cap, int run,
+                          int* __restrict__ arrivals, int nTotal)
 {
    const int lane = threadIdx.x & 63;
    const int wrun = uniform(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -228,7 +230,7 @@ void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restri
       const int k = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const int c = first + wrun * run + k;
-      int n = uniform(nAtoms[c]);
+      int n = uniform(nAtoms[c] + arrivals[c] + arrivals[nTotal + c] + arrivals[2 * (size_t)nTotal + c]);
       if (n > cap) n = cap;
       const size_t o = (size_t)c * cap + lane;
       int key = 0x7fffffff, spec = 0;
@@ -247,7 +249,7 @@ void CompactSortCellsWave(AtomArrays at, int* __restrict__ nAtoms, int* __restri
          at.gid[d] = key; at.spec[d] = spec;
          at.rx[d] = x; at.ry[d] = y; at.rz[d] = z; at.px[d] = px; at.py[d] = py; at.pz[d] = pz;
       }
-      if (lane == 0) { nAtoms[c] = live; dirty[c] = 0; }
+      if (lane == 0) { nAtoms[c] = live; dirty[c] = 0; arrivals[c] = 0; arrivals[nTotal + c] = 0; arrivals[2 * (size_t)nTotal + c] = 0; }
    }
 }
 
@@ -458,4 +460,62 @@ void MirrorSlotCells(int kind, int nPairs, const int* __restrict__ dst, const in
    const size_t to = (size_t)d * cap + threadIdx.x, from = (size_t)c * cap + threadIdx.x;
    if (kind == 0) dfEmbed[to] = dfEmbed[from];
    else { rx[to] = rx[from] + shift[3 * k]; ry[to] = ry[from] + shift[3 * k + 1]; rz[to] = rz[from] + shift[3 * k + 2]; }
+}
+
+// Atoms on a self-neighbour axis: pack + unpack of both faces of an axis phase as ONE kernel, no message, no scan.  Every atom of the send cells (the halo
+// layer and the first local layer of either face, mkAtomCellList) is displaced by the shift of its face, finds its cell from the displaced coordinates and is
+// appended there -- the arithmetic and the membership of the message path (LoadAtomsBufferPacked + UnloadAtomsBufferPacked), so the cells end up holding the
+// same atoms and CompactSortCells the same order.  The message path packs both faces BEFORE it unpacks either, and the cells an atom arrives in are send
+// cells of the opposite face: arrivals are therefore counted beside the cell (arrivals[axis][cell]), not in nAtoms -- a cell's content at the start of the
+// phase is nAtoms + the arrivals of the EARLIER mirrored axes, stable for the whole launch.  CompactSortCells folds the counts back into nAtoms.
+struct MirrorAtomsJob { const int* list[2]; int nCells[2]; real_t sx[2], sy[2], sz[2]; };
+
+__global__ __launch_bounds__(256)
+void MirrorAtomCells(MirrorAtomsJob jb, AtomArrays at, const int* __restrict__ nAtoms, int* __restrict__ arrivals, int nTotal, int firstAxis, int axis,
+                     int* __restrict__ dirty, int* __restrict__ status, LinkCellGpu boxes, int cap)
+{
+   const int face = blockIdx.y;
+   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+   const int i = (int)(tid / cap), slot = (int)(tid - (long)i * cap);
+   bool have = i < jb.nCells[face];
+   int c = 0;
+   if (have) {
+      c = jb.list[face][i];
+      int cnt = nAtoms[c];
+      for (int a = firstAxis; a < axis; ++a) cnt += arrivals[(size_t)a * nTotal + c];
+      have = slot < (cnt < cap ? cnt : cap);
+   }
+   const size_t o = (size_t)c * cap + slot;
+   real_t x = R(0.0), y = R(0.0), z = R(0.0);
+   int d = -1;
+   if (have) {
+      x = at.rx[o] + jb.sx[face]; y = at.ry[o] + jb.sy[face]; z = at.rz[o] + jb.sz[face];
+      const CellGeom g = makeGeom(boxes);
+      if (!comdCoordInHalo(&g, x, y, z)) { atomicOr(&status[1], 1); have = false; }
+      else d = comdBoxFromCoord(&g, x, y, z);
+   }
+   // one atomic per distinct destination cell per wave (the atoms of a send cell nearly all go to one cell)
+   int at0 = 0;
+   for (bool pending = have; __builtin_amdgcn_ballot_w64(pending) != 0ull; ) {
+      const unsigned long long todo = __builtin_amdgcn_ballot_w64(pending);
+      const int lead = __builtin_amdgcn_readlane(d, __ffsll((long long)todo) - 1);
+      if (pending && d == lead) {
+         const unsigned long long m = __builtin_amdgcn_ballot_w64(true);
+         const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+         int base = 0;
+         if (rank == 0) base = atomicAdd(&arrivals[(size_t)axis * nTotal + lead], __popcll(m));
+         at0 = __builtin_amdgcn_readfirstlane(base) + rank;
+         pending = false;
+      }
+   }
+   if (!have) return;
+   int start = nAtoms[d];
+   for (int a = firstAxis; a < axis; ++a) start += arrivals[(size_t)a * nTotal + d];
+   const int k = start + at0;
+   if (k >= cap) { atomicOr(&status[0], 1); return; }
+   const size_t to = (size_t)d * cap + k;
+   at.gid[to] = at.gid[o]; at.spec[to] = at.spec[o];
+   at.rx[to] = x; at.ry[to] = y; at.rz[to] = z;
+   at.px[to] = at.px[o]; at.py[to] = at.py[o]; at.pz[to] = at.pz[o];
+   dirty[d] = 1;
 }

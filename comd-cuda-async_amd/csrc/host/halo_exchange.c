@@ -175,6 +175,18 @@ static void destroyAtomsExchange(void* vparms)
    comdDeviceFree(parms->d_cellOffsets); comdDeviceFree(parms->d_cellOffsets2);
 }
 
+/* self-neighbour tail of the atom exchange: one launch per axis, in order (an axis re-sends what the earlier ones brought in) */
+static void atomsMirror(HaloExchange* hh, void* vdata, int firstAxis)
+{
+   AtomExchangeParms* parms = (AtomExchangeParms*)hh->parms;
+   SimFlat* sim = (SimFlat*)vdata;
+   for (int a = firstAxis; a < 3; ++a) {
+      const int n[2] = { parms->nCells[2 * a], parms->nCells[2 * a + 1] };
+      int* const lists[2] = { parms->cellListGpu[2 * a], parms->cellListGpu[2 * a + 1] };
+      mirrorAtomCellsGpu(n, lists, parms->shift[2 * a], parms->shift[2 * a + 1], firstAxis, a, &sim->gpu, sim->gpu.boundary_stream);
+   }
+}
+
 HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDevice)
 {
    HaloExchange* hh = initHaloExchangeBase(domain);
@@ -200,6 +212,7 @@ HaloExchange* initAtomHaloExchange(Domain* domain, LinkCell* boxes, int allocDev
    hh->type = 0;
    hh->parms = parms;
    hh->deviceBuffers = allocDevice;
+   hh->nTotalBoxes = boxes->nTotalBoxes; if (allocDevice) hh->mirror = atomsMirror;
    hh->msgHeaderBytes = COMD_ATOM_MSG_HEADER; hh->msgBytesPerAtom = COMD_ATOM_MSG_BYTES_PER_ATOM; hh->capacityAtoms = parms->capacityAtoms;
    hh->countPtrs = atomsCountPtrs; hh->setBounds = atomsSetBounds;
    if (allocDevice) {

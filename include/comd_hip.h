@@ -28,28 +28,32 @@ extern "C" {
 
 /* mytype.h:8-21: one build per precision.  -DCOMD_SINGLE (make PRECISION=single -> libcomd_hip_sp.so / libcomd_host_sp.so) makes every
  * position, momentum, force, energy, table sample and message field a float, as the reference's DOUBLE_PRECISION = OFF build does. */
+/* (next to the reference's own mytype.h / defines.h -- a reference host file compiled against include/comd_hip_shim.h -- their definitions of the same
+ * names stand: same types, same values) */
+#ifndef __MYTYPE_H_
 #ifdef COMD_SINGLE
 typedef float real_t;
 #else
 typedef double real_t;                 /* mytype.h:16 (COMD_DOUBLE build) */
 #endif
+typedef struct vec_t { real_t* x; real_t* y; real_t* z; } vec_t;          /* mytype.h:24-28 */
+#endif
 typedef void*  comdStream_t;
 
-typedef struct vec_t { real_t* x; real_t* y; real_t* z; } vec_t;          /* mytype.h:24-28 */
-
-/* force-kernel variants, defines.h:11-17 (the *_NL and warp_atom values are accepted and mapped
- * to thread_atom; they are outside the hot-path scope) */
+/* force-kernel variants, defines.h:11-17 (warp_atom runs as thread_atom, warp_atom_nl as thread_atom_nl) */
+#ifndef __DEFINES_H_
 enum { THREAD_ATOM = 0, THREAD_ATOM_NL = 1, WARP_ATOM = 2, WARP_ATOM_NL = 3, CTA_CELL = 4, CPU_NL = 5 };
+#endif
 
 /* gpu_types.h:48-58 */
-typedef struct InterpolationObjectGpu {
+typedef struct InterpolationObjectGpuSt {
    int     n;
    real_t  x0, xn, invDx, invDxHalf, invDxXx0;
    real_t* values;                     /* device, n+3 entries, values[0] is the leading pad */
 } InterpolationObjectGpu;
 
 /* gpu_types.h:72-79 */
-typedef struct LjPotentialGpu {
+typedef struct LjPotentialGpuSt {
    real_t cutoff, sigma, epsilon;
    /* thread_atom: before each force evaluation every full wave (64 consecutive slots of a cell) gets the list of the stencil atoms that lie
     * within the cutoff of the bounding box of its atoms; the force kernel tests only those.  Allocated by the first thread_atom launch. */
@@ -65,14 +69,14 @@ typedef struct LjPotentialGpu {
 
 /* gpu_types.h:60-69: cubic spline in r^2 (-P, `spline` argument of eamForce*Gpu): coefficients {a,b,c,d} per table interval,
  * f(r) = ((a r2 + b) r2 + c) r2 + d; the interval is picked with single-precision arithmetic as in the reference */
-typedef struct InterpolationSplineObjectGpu {
+typedef struct InterpolationSplineObjectGpuSt {
    int     n;
    float   x0, xn, invDx, invDxXx0;
    real_t* coefficients;               /* device, 4 * n */
 } InterpolationSplineObjectGpu;
 
 /* gpu_types.h:81-96 */
-typedef struct EamPotentialGpu {
+typedef struct EamPotentialGpuSt {
    real_t cutoff;
    InterpolationObjectGpu phi, rho, f;
    InterpolationSplineObjectGpu phiS, rhoS;   /* allocated when GpuConfig.phiSpline / rhoSpline are given; F(rhobar) stays quadratic (gpu_utility.c:443) */
@@ -104,7 +108,7 @@ typedef struct EamPotentialGpu {
 } EamPotentialGpu;
 
 /* gpu_types.h:98-112 */
-typedef struct LinkCellGpu {
+typedef struct LinkCellGpuSt {
    int    nLocalBoxes, nTotalBoxes;
    int    gridSize[3];
    real_t localMin[3], localMax[3], invBoxSize[3];
@@ -116,7 +120,7 @@ typedef struct LinkCellGpu {
 /* gpu_types.h:120-146 NeighborListGpu.  Verlet lists for the *_nl methods: every atom within cutoff + skinDistance of a local
  * atom, valid until some atom has moved more than skinDistance/2 since the build.  An entry is the neighbour's global slot:
  * between builds no atom changes slot (nothing is re-binned, halo copies are refreshed in place). */
-typedef struct NeighborListGpu {
+typedef struct NeighborListGpuSt {
    int*   list;                        /* device [nLocalBoxes * maxNeighbors * maxAtoms]: entry k of atom i of cell c at (c*maxNeighbors + k)*maxAtoms + i */
    int*   nNeighbors;                  /* device [nLocalBoxes * maxAtoms] */
    int    maxNeighbors;                /* rows per cell (gpu_neighborList.c:50 MAXNEIGHBORLISTSIZE) */
@@ -147,7 +151,7 @@ typedef struct NeighborListGpu {
 } NeighborListGpu;
 
 /* gpu_types.h:148-157 */
-typedef struct AtomsGpu {
+typedef struct AtomsGpuSt {
    vec_t   r, p, f;                    /* device SoA, [nTotalBoxes*maxAtoms] each */
    real_t* e;
    int*    iSpecies;
@@ -156,10 +160,10 @@ typedef struct AtomsGpu {
 } AtomsGpu;
 
 /* gpu_types.h:38-45: the reference's gid -> slot hash table of its list mode.  Counters only here (atoms keep their slots between builds). */
-typedef struct HashTableGpu { int nMaxEntries, nEntriesPut, nEntriesGet; } HashTableGpu;
+typedef struct HashTableGpuSt { int nMaxEntries, nEntriesPut, nEntriesGet; } HashTableGpu;
 
 /* gpu_types.h:159-190.  Passed by pointer everywhere (the reference passes 856 bytes by value). */
-typedef struct SimGpu {
+typedef struct SimGpuSt {
    int          maxAtoms;              /* slot capacity of a link cell (Makefile:16 MAXATOMS) */
    int          max_atoms_cell;        /* largest occupancy last seen by updateNAtomsCpu (gpu_types.h:160); 0 = unknown */
    int          deviceId, rank;
@@ -180,6 +184,7 @@ typedef struct SimGpu {
    /* redistribution scratch (CoMDTypes.h:123-126 flags/tmp_sort) */
    int*         nAtomsPrev;            /* device [nTotalBoxes]: occupancy snapshot */
    int*         cellDirty;             /* device [nTotalBoxes]: membership changed, needs compaction + gid sort */
+   int*         cellArrivals;          /* device [3][nTotalBoxes]: atoms mirrorAtomCellsGpu appended to a cell in the phase of axis a, counted beside nAtoms until the next sort */
    int*         status;                /* device [4]: {cell overflow / stencil too large, lost atom, msg overflow or outgrown bound, EAM row / list overflow} */
    real_t*      reduceBuf;             /* device: per-block partial sums for computeEnergy */
    real_t*      pinned;                /* pinned host staging (energies, counts) */
@@ -199,9 +204,10 @@ typedef struct SimGpu {
    void*        statusEvent;           /* comdPollStatus: recorded behind the last status mirror (pinned[32..35]), NULL before the first poll */
    int*         adapterScan;
    int          adapterScanCap;
-   /* fields the reference's host code assigns (timestep.c:229-236); kept so that those statements compile, not read by the library */
+   /* fields the reference's host code assigns (timestep.c:229-236, :329, :350); kept so that those statements compile, not read by the library */
    HashTableGpu d_hashTable;
    int          genPairlist;
+   int*         d_updateLinkCellsRequired;   /* device [1], zero: the reference's list mode copies it back to ask "did an atom change cells?" (timestep.c:329) */
 } SimGpu;
 
 /* Everything AllocateGpu needs to know about the rank's geometry and potential.
@@ -249,6 +255,14 @@ void CopyDataToGpu(SimGpu* sim, const HostAtoms* host);
 void GetDataFromGpu(SimGpu* sim, HostAtoms* host);
 /* updateNAtomsCpu(SimFlat*), gpu_utility.c: refresh the host copy of nAtoms (CoMD.c:445-452 reads it) */
 void updateNAtomsCpu(SimGpu* sim, int* nAtomsHost);
+/* The staging entry points of gpu_utility.h:60-69 that the reference's cpu_nl path and DEBUG blocks use (timestep.c:309).  Where the reference passes
+ * SimFlat*, the device library takes its own SimGpu* and the host arrays as a HostAtoms (as CopyDataToGpu / GetDataFromGpu do). */
+void cudaCopyDtH(void* dst, const void* src, int size);                         /* gpu_utility.c:46-49: identical signature */
+void GetLocalAtomsFromGpu(SimGpu* sim, HostAtoms* host);                        /* gpu_utility.c:656-673: p, r, gid of the local cells -> host */
+void updateGpuHalo(SimGpu* sim, const HostAtoms* host);                         /* gpu_utility.c:714-757: p, r, gid, iSpecies of the halo cells -> device */
+void updateNAtomsGpu(SimGpu* sim, const int* nAtomsHost);                       /* gpu_utility.c:602-605 */
+/* gpu_utility.c:678-712 (host code there too): the halo cells' atoms as one SoA message (no header) + the scan of their occupancies; returns the atom count */
+int  compactHaloCells(const HostAtoms* host, int nLocalBoxes, int nTotalBoxes, int maxAtoms, char* h_compactAtoms, int* h_cellOffset);
 /* DestroyGpu(SimFlat*), gpu_utility.c:284-347 */
 void DestroyGpu(SimGpu* sim);
 /* initLinkCellsGpu(SimFlat*, LinkCellGpu*), gpu_utility.c:757-790: geometry + occupancy array of the device link cells (AllocateGpu calls it) */
@@ -343,11 +357,14 @@ void sortAtomsGpu(SimGpu* sim, comdStream_t stream);
  * format (gpu_kernels.cu:506-517 getAtomMsgSoAPtr): int gid[n]; int type[n]; real_t rx[n],ry[n],rz[n],px[n],py[n],pz[n]. */
 #define COMD_ATOM_MSG_HEADER 16
 #define COMD_ATOM_MSG_BYTES_PER_ATOM (8 + 6 * (int)sizeof(real_t))     /* 56 in the double build = sizeof(AtomMsg), haloExchange.h:32-38 */
-typedef struct AtomMsgSoA {            /* haloExchange.h AtomMsgSoA */
+#ifndef __HALO_EXCHANGE_                /* (next to the reference's haloExchange.h, its definition of the same struct -- the same eight pointers -- stands) */
+typedef struct AtomMsgSoASt {          /* haloExchange.h:39-47 AtomMsgSoA */
    int *gid, *type; real_t *rx, *ry, *rz, *px, *py, *pz;
 } AtomMsgSoA;
+#endif
+struct AtomMsgSoASt;
 /* getAtomMsgSoAPtr(buffer, &msg, n), gpu_kernels.cu:506-517; buffer points at the header */
-void getAtomMsgSoAPtr(char* buffer, AtomMsgSoA* atomMsg, int n);
+void getAtomMsgSoAPtr(char* buffer, struct AtomMsgSoASt* atomMsg, int n);
 /* compactCellsGpu(work_d, nCells, d_cellList, sim, d_cellOffsets, d_workScan, shift, stream), gpu_kernels.cu:519-551:
  * exclusive-scan the occupancies of the listed cells and gather their atoms (positions shifted by `shift`) into
  * the message at work_d, in cell-list order.  d_cellOffsets needs nCells+1 ints.  Nothing is copied to the host and
@@ -431,8 +448,9 @@ void emptyNeighborListGpu(SimGpu* sim, int boundaryFlag);
 /* neighborListUpdateRequiredGpu(SimGpu*), gpu_kernels.cu:1449-1484: 1 when forceRebuildFlag is set or some local atom has moved
  * more than skin/2 since the build (blocking read of one flag).  THIS rank's answer; the caller reduces over ranks. */
 int  neighborListUpdateRequiredGpu(SimGpu* sim);
-/* neighborListForceRebuildGpu(NeighborListGpu*), gpu_neighborList.c:88-93 */
-void neighborListForceRebuildGpu(SimGpu* sim);
+/* neighborListForceRebuildGpu(NeighborListGpu*), gpu_neighborList.c:88-93: the reference's signature (a host function there; an object of the
+ * reference that defines it too simply takes precedence over the library's) */
+void neighborListForceRebuildGpu(NeighborListGpu* neighborList);
 /* buildNeighborListGpu(SimGpu*, method, boundaryFlag), gpu_kernels.cu:1975-2029: list every atom within cutoff + skin of each
  * local atom (cells must be current: call after the atom exchange), snapshot lastR, clear forceRebuildFlag.
  * boundaryFlag is accepted for signature parity (BOTH = 0 is the only mode the reference enables, timestep.c:59-82). */
@@ -478,6 +496,11 @@ void unloadPositionBufferToGpu2(const real_t* bufA, const real_t* bufB, const in
 /* [round 4] Axes on which a rank is its own neighbour (all three on one rank): the halo cells are filled straight from the cells they are images of, one
  * launch for every such axis at the end of the x -> y -> z sequence instead of a pack and an unpack per axis (same values: haloExchange.c:788-853 is the
  * reference's self-neighbour branch, :1504-1520 the ordering the host folds into one source per halo cell).  kind 0: dfEmbed, 1: positions + d_shift[3k..]. */
+/* the atom exchange of a self-neighbour axis (both faces): every atom of the send cells is displaced, binned by its coordinates and appended -- pack and
+ * unpack of gpu_redistribute.h:376-402, 499-620 in one launch.  firstAxis: the first axis of the mirrored tail (arrivals of the axes firstAxis..axis-1 count as
+ * content of a cell); sortAtomsGpu afterwards, as after the message path. */
+void mirrorAtomCellsGpu(const int nCells[2], int* const d_cellList[2], const real_t shiftM[3], const real_t shiftP[3], int firstAxis, int axis,
+                        SimGpu* sim, comdStream_t stream);
 void mirrorSlotCellsGpu(int kind, int nPairs, const int* d_dst, const int* d_src, const real_t* d_shift, SimGpu* sim, comdStream_t stream);
 
 /* ---- device-side timing for bench.py -------------------------------------------------------- */

@@ -20,14 +20,36 @@
 #include <limits.h>
 #include "comd_hip.h"
 
-/* ---- CUDA runtime names used by the hot-path host files ---------------------------------------------------------- */
+/* ---- CUDA runtime names used by the hot-path host files (ljForce.c, eam.c, timestep.c, haloExchange.c + the headers they include) ------------------ */
+#include <stddef.h>
 typedef comdStream_t cudaStream_t;
+typedef void* cudaEvent_t;                              /* haloExchange.h:132 (a field of the libmp exchange state; never used on the plain path) */
+typedef int cudaError_t;                                /* libcomd_hip reports HIP errors itself (message + exit(-1), as CUDA_CHECK does): calls here always succeed */
+enum { cudaSuccess = 0 };
 enum { cudaMemcpyHostToHost = 0, cudaMemcpyHostToDevice = 1, cudaMemcpyDeviceToHost = 2, cudaMemcpyDeviceToDevice = 3 };
-#define cudaStreamSynchronize(s)              comdStreamSynchronize(s)
-#define cudaDeviceSynchronize()               comdDeviceSynchronize()
-#define cudaMemset(p, v, n)                   comdDeviceMemset((p), (v), (long)(n))
-#define cudaMemcpyAsync(dst, src, n, kind, s) comdMemcpyAsync((dst), (src), (long)(n), (kind), (s))
-#define cudaMemcpy(dst, src, n, kind)         comdMemcpyAsync((dst), (src), (long)(n), (kind), (comdStream_t)0)
+enum { cudaHostRegisterDefault = 0, cudaHostRegisterPortable = 1, cudaHostRegisterMapped = 2 };
+static inline const char* cudaGetErrorString(cudaError_t e) { (void)e; return "no error (libcomd_hip exits with the HIP error string on its own)"; }
+static inline cudaError_t comdShimOk(void) { return cudaSuccess; }
+#define cudaStreamSynchronize(s)              (comdStreamSynchronize(s), comdShimOk())
+#define cudaDeviceSynchronize()               (comdDeviceSynchronize(), comdShimOk())
+#define cudaMemset(p, v, n)                   (comdDeviceMemset((p), (v), (long)(n)), comdShimOk())
+#define cudaMemcpyAsync(dst, src, n, kind, s) (comdMemcpyAsync((dst), (src), (long)(n), (kind), (s)), comdShimOk())
+#define cudaMemcpy(dst, src, n, kind)         (comdMemcpyAsync((dst), (src), (long)(n), (kind), (comdStream_t)0), comdStreamSynchronize((comdStream_t)0), comdShimOk())
+/* haloExchange.c:229-266, 295-308, 384-467 (buffers and cell lists of the exchange), :1698-1701, :1908-1914 */
+static inline cudaError_t comdShimMalloc(void** p, size_t n)     { *p = comdDeviceMalloc((long)n); return cudaSuccess; }
+static inline cudaError_t comdShimMallocHost(void** p, size_t n) { *p = comdHostMallocPinned((long)n); return cudaSuccess; }
+#define cudaMalloc(p, n)            comdShimMalloc((void**)(p), (size_t)(n))
+#define cudaMallocHost(p, n)        comdShimMallocHost((void**)(p), (size_t)(n))
+#define cudaFree(p)                 (comdDeviceFree((void*)(p)), comdShimOk())
+#define cudaFreeHost(p)             (comdHostFreePinned((void*)(p)), comdShimOk())
+#define cudaHostRegister(p, n, f)   comdShimOk()       /* haloExchange.c:215-218: the host buffers stay pageable; comdMemcpyAsync copies them either way */
+
+/* nvToolsExt.h as haloExchange.c:60-91 uses it (PUSH_RANGE / POP_RANGE around the exchange phases): profiler range markers, no effect on the computation.
+ * rocprofv3 sees the kernels by name; the markers compile to nothing. */
+typedef struct { int version, size, colorType; unsigned color; int messageType; struct { const char* ascii; } message; } nvtxEventAttributes_t;
+enum { NVTX_VERSION = 0, NVTX_EVENT_ATTRIB_STRUCT_SIZE = 0, NVTX_COLOR_ARGB = 0, NVTX_MESSAGE_TYPE_ASCII = 0 };
+static inline int nvtxRangePushEx(const nvtxEventAttributes_t* a) { (void)a; return 0; }
+static inline int nvtxRangePop(void) { return 0; }
 
 /* MAXATOMS is a -D macro in the reference (Makefile:16); here it is a run-time value.  Usable inside functions that have the
  * simulation in scope under the reference's usual names (`sim` or `s`): define COMD_SHIM_SIM to that name before including. */
@@ -61,6 +83,7 @@ typedef real_t real3_old[3];
  * the interior cells' force work on ANOTHER stream right after it.  The library's call only enqueues, so the adapter adds the wait. */
 #define updateLinkCellsGpu(sim)       ((updateLinkCellsGpu)(&(sim)->gpu, (sim)->boundary_stream), comdStreamSynchronize((sim)->boundary_stream))     /* timestep.c:234, 246 */
 #define buildAtomListGpu(sim, stream) (buildAtomListGpu)(&(sim)->gpu, (stream))                     /* timestep.c:244, 271 */
+#define emptyHaloCellsGpu(sim)        (emptyHaloCellsGpu)(&(sim)->gpu, (sim)->boundary_stream)       /* timestep.c:282, 340 */
 #define sortAtomsGpu(sim, stream)     (sortAtomsGpu)(&(sim)->gpu, (stream))                         /* timestep.c:248, 274 */
 
 /* ---- halo pack / unpack: gpu_kernels.h:28, 70-72 ----------------------------------------------------------------------

@@ -40,11 +40,13 @@ SURFACE = {
     # gpu_utility.h:55-69
     **{n: IMPLEMENTED for n in ("SetupGpu", "AllocateGpu", "CopyDataToGpu", "SetBoundaryCells", "GetDataFromGpu", "DestroyGpu", "emptyHaloCellsGpu",
                                 "initLinkCellsGpu")},
+    # [round 4] the rest of gpu_utility.h:60-69 (staging of the cpu_nl path and the DEBUG block of timestep.c:309): all real
+    **{n: IMPLEMENTED for n in ("GetLocalAtomsFromGpu", "updateGpuHalo", "updateNAtomsGpu", "updateNAtomsCpu", "cudaCopyDtH", "compactHaloCells")},
 }
 
 
 def test_link_surface_is_fully_defined(pkg):
-    assert len(SURFACE) == 52 + 8                        # 49 undefined symbols (+3 with -DDO_MPI) + the gpu_utility.c entry points
+    assert len(SURFACE) == 52 + 8 + 6                    # 49 undefined symbols (+3 with -DDO_MPI) + the gpu_utility.c entry points + the staging names of gpu_utility.h:60-69
     lib = pkg.lib_hip()
     missing = [n for n in SURFACE if not hasattr(lib, n)]
     assert not missing, missing
@@ -83,6 +85,56 @@ def test_reference_call_expressions_compile_and_link(tmp_path):
     undefined = {line.split()[-1] for line in syms.splitlines() if " U " in line}
     assert {"ljForceGpu", "eamForce1GpuAsync", "eamForce3Gpu", "advanceVelocityGpu", "advancePositionGpu", "computeEnergy", "updateLinkCellsGpu", "sortAtomsGpu",
             "compactCellsGpu", "unloadAtomsBufferToGpu", "loadForceBufferFromGpu", "unloadForceBufferToGpu", "pairlistUpdateRequiredGpu"} <= undefined
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's REAL host files through the shim (build container only: /root/reference does not exist on the GPU box, and nothing of it is copied).
+REFERENCE = "/root/reference/src-mpi"
+HOT_PATH_FILES = ("ljForce", "timestep", "eam", "haloExchange")                   # the four host files of the hot path
+OTHER_HOST_FILES = ("neighborList", "hashTable", "linkCells", "initAtoms", "mytype")   # reference host code the four call into (its CPU list path); no device-library call in them
+
+
+@pytest.mark.skipif(not os.path.isdir(REFERENCE) or shutil.which("gcc") is None, reason="needs the reference checkout (build container) and gcc")
+def test_reference_host_files_compile_and_link_against_the_shim(tmp_path):
+    """COMPILE AND LINK ONLY -- nothing built here is ever run, and it is no oracle.  The reference's ljForce.c, timestep.c, eam.c and haloExchange.c, as
+    they lie (symlinked into a scratch directory so that `#include "gpu_types.h"` etc. resolve to five one-line headers that include
+    include/comd_hip_shim.h in the place of cuda_runtime.h / nvToolsExt.h / gpu_kernels.h / gpu_utility.h / gpu_types.h), must compile without an error,
+    every device-library symbol they leave undefined must be one libcomd_hip.so defines, and together with the reference's own host files they call into
+    they must link against libcomd_hip.so + libcomd_host.so with --no-undefined (libcomd_host.so stands in for the reference's parallel.c /
+    performanceTimers.c / decomposition.c, same names and signatures)."""
+    src = tmp_path / "src"
+    inc = tmp_path / "inc"
+    src.mkdir(); inc.mkdir()
+    redirected = ("gpu_kernels.h", "gpu_utility.h", "gpu_types.h")
+    for f in os.listdir(REFERENCE):
+        if f.endswith((".c", ".h")) and f not in redirected:
+            os.symlink(os.path.join(REFERENCE, f), src / f)
+    for h in redirected:
+        (src / h).write_text('#include "comd_hip_shim.h"\n')
+    for h in ("cuda_runtime.h", "nvToolsExt.h"):
+        (inc / h).write_text('#include "comd_hip_shim.h"\n')
+    mpi_inc = "/opt/conda/include"                                                 # comm.h:3 includes <mpi.h> for its prototypes' MPI_Comm (MPICH ships in the image)
+    if not os.path.exists(os.path.join(mpi_inc, "mpi.h")):
+        pytest.skip("no mpi.h in this image (comm.h needs MPI_Comm)")
+    flags = ["gcc", "-std=gnu11", "-O1", "-fPIC", "-w", "-DCOMD_DOUBLE", "-DNDEBUG", "-DMAXATOMS=64", "-I" + str(inc), "-I" + os.path.join(ROOT, "include"), "-I" + mpi_inc]
+    objs = []
+    for f in HOT_PATH_FILES + OTHER_HOST_FILES:
+        obj = str(tmp_path / (f + ".o"))
+        cc = subprocess.run(flags + ["-c", str(src / (f + ".c")), "-o", obj], capture_output=True, text=True)
+        assert cc.returncode == 0, f"{f}.c: " + cc.stderr[-3000:]
+        objs.append(obj)
+    hip_defined = {l.split()[-1] for l in subprocess.run(["nm", "-D", "--defined-only", os.path.join(CSRC, "libcomd_hip.so")], capture_output=True, text=True).stdout.splitlines() if l.strip()}
+    wanted = set()
+    for obj in objs[:len(HOT_PATH_FILES)]:
+        wanted |= {l.split()[-1] for l in subprocess.run(["nm", "-u", obj], capture_output=True, text=True).stdout.splitlines() if l.strip()}
+    device_calls = wanted & (set(SURFACE) | {n for n in hip_defined if n.startswith("comd")})
+    assert device_calls <= hip_defined, sorted(device_calls - hip_defined)
+    assert {"ljForceGpu", "eamForce1Gpu", "eamForce3GpuAsync", "advanceVelocityGpu", "advancePositionGpu", "computeEnergy", "updateLinkCellsGpu", "sortAtomsGpu",
+            "compactCellsGpu", "unloadAtomsBufferToGpu", "loadForceBufferFromGpu", "unloadForceBufferToGpu", "emptyHaloCellsGpu", "pairlistUpdateRequiredGpu"} <= device_calls
+    assert "neighborListForceRebuildGpu" in wanted and "neighborListForceRebuildGpu" in hip_defined          # (gpu_neighborList.h:55: host code in the reference, same signature here)
+    ld = subprocess.run(["gcc", "-shared", "-o", str(tmp_path / "libreference_host.so")] + objs + ["-L" + CSRC, "-lcomd_host", "-lcomd_hip", "-Wl,--no-undefined", "-Wl,-rpath," + CSRC, "-lm"],
+                        capture_output=True, text=True)
+    assert ld.returncode == 0, ld.stderr[-4000:]
 
 
 # ---------------------------------------------------------------------------------------------------------------------
