@@ -19,7 +19,7 @@ Extra objects on the JSON line:
   variants     : N = 1 only: the same K timed steps with the other force methods (cta_cell, the Verlet-list method
                  thread_atom_nl) and the other potential, for comparison; `value` is always the named configuration.
                  The BASELINE.json configurations among them (EAM 80^3 cta_cell = configs[2]) carry a `roofline` object of their own.
-  target_line  : N = 1 only: BASELINE.json's north_star line, LJ 256^3 (67 M atoms) thread_atom, 3 timed steps after 1 -- value, ms/step,
+  target_line  : N = 1 only: BASELINE.json's north_star line, LJ 256^3 (67 M atoms) thread_atom, 10 timed steps after 2 -- value, ms/step,
                  kernel and whole-evaluation ms, HBM and fp64 fractions, memory of the candidate lists; skipped with a stated reason when
                  the device has less than 60 GB free.
 
@@ -52,7 +52,8 @@ FORCE_FLOP_LISTED = {"lj": 2350 * 8 + 550 * 25}
 FORCE_FLOP_NL = {"lj": 732 * 8 + 550 * 25, "eam": 2 * (57 * 8 + 42 * 70)}
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0                 # wave-instructions/s the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction
 KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell_boxes", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs", ("lj", "cta_cell_pairlist"): "LJ_Force_cta_cell",
-               ("eam", "thread_atom"): "EAM_Force_thread_atom", ("eam", "cta_cell"): "EAM_Force_cta_brick<1> + <3>", ("eam", "thread_atom_nl"): "EAM_Force_nl_lds"}
+               ("eam", "thread_atom"): "EAM_Force_thread_atom", ("eam", "cta_cell"): "EAM_Force_cta_brick<1> + <3>",
+               ("eam", "thread_atom_nl"): "EAM_Force_cta_brick<1, listed> + <3, listed> (Verlet rows)"}
 
 
 def parse():
@@ -116,24 +117,43 @@ def cpu_baseline(pot, seconds):
 
     rate, used, steps, loop, n_atoms = leg(min(cores, 16), seconds * 0.5)      # the GPU box gives one GPU a 16-core share
     rate1, _, steps1, loop1, _ = leg(1, seconds * 0.5)
-    return {"value": rate, "unit": "atom-updates/s", "cores": used, "kind": "port",
-            "sample": f"{pot.upper()} Cu {n}^3 FCC ({n_atoms} atoms), {steps} steps, oracle/comd_oracle.c (27-cell stencil form, OpenMP), {loop:.1f} s",
-            "one_core": {"value": rate1, "unit": "atom-updates/s", "cores": 1,
-                         "sample": f"same workload, {steps1} steps, 1 thread (the reference runs one thread per rank), {loop1:.1f} s"}}
+    # the headline figure is ONE core: the reference runs one thread per rank ("Threading: none", yamlOutput.c:87; SURVEY.md 8d "1 core for C1"); the share of the
+    # host cores this GPU gets (OpenMP over cells) is reported beside it
+    return {"value": rate1, "unit": "atom-updates/s", "cores": 1, "kind": "port",
+            "sample": f"{pot.upper()} Cu {n}^3 FCC ({n_atoms} atoms), {steps1} steps, oracle/comd_oracle.c (27-cell stencil form), 1 thread, {loop1:.1f} s",
+            "all_cores_of_this_gpu": {"value": rate, "unit": "atom-updates/s", "cores": used,
+                                      "sample": f"same workload, {steps} steps, OpenMP over cells on {used} threads, {loop:.1f} s"}}
 
 
 def profiled(pot, method, nx):
     """The committed rocprofv3 PMC passes for this workload (profiles/rNN_traffic.json, newest round first): HBM-side bytes (FETCH_SIZE + WRITE_SIZE) and VALU
     wave-instructions per force evaluation.  PMC counters cannot be read from inside the timed process, so these are the last profiled values, and the
     record says which file they come from."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             rec = json.load(open(os.path.join(ROOT, "profiles", name))).get(f"{pot}/{method}/{nx}")
         except (OSError, ValueError):
             rec = None
         if rec:
+            # a record made for another version of the kernel must not be divided by this run's time: profiles/rNN_summarize.py stores a hash of the kernel's
+            # source header with every record; a record whose hash is not the current one is reported as stale, not used
+            if rec.get("kernel_source_sha16") and rec["kernel_source_sha16"] != kernel_source_hash(pot, method):
+                return None, f"profiles/{name} (STALE: collected for another version of the kernel source; re-run profiles/r04_collect.sh)"
             return rec, f"profiles/{name}"
     return None, None
+
+
+KERNEL_SOURCES = {("lj", "thread_atom"): ["lj_kernels.h"], ("lj", "cta_cell"): ["lj_kernels.h"], ("lj", "cta_cell_pairlist"): ["lj_kernels.h"], ("lj", "thread_atom_nl"): ["nl_kernels.h"],
+                  ("eam", "cta_cell"): ["eam_brick_kernels.h"], ("eam", "thread_atom_nl"): ["eam_brick_kernels.h"], ("eam", "thread_atom"): ["eam_kernels.h"]}
+
+
+def kernel_source_hash(pot, method):
+    """sha256 (first 16 hex digits) of the header(s) that hold the force kernel of this path: what a stored PMC record is valid for."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES[(pot, method)]:
+        h.update(open(os.path.join(ROOT, "comd-cuda-async_amd", "csrc", "hip", name), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def roofline_object(pot, method, nx, n_local, force_ms, aux_ms, precision, one_gpu=True):
@@ -148,7 +168,7 @@ def roofline_object(pot, method, nx, n_local, force_ms, aux_ms, precision, one_g
     out = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": (achieved / HBM_PEAK_GBS) if achieved else None,
            "traffic": (rec["fetch_KiB"] + rec["write_KiB"]) * 1024.0 if rec and precision == "double" else None,
            "traffic_provenance": (f"{prov}: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, raw counter values summed over the launches of one force "
-                                  "evaluation -- a stored value, not this run's") if rec and precision == "double" else None,
+                                  "evaluation -- a stored value, not this run's") if rec and precision == "double" else prov,
            "kernel": KERNEL_NAME[(pot, method)], "kernel_ms_per_step": force_ms,
            "force_evaluation_ms": force_ms + aux_ms,      # every launch of one force call: the kernel(s) + list build / cell marks
            "algorithmic_bytes_per_atom": FORCE_BYTES[pot],
@@ -201,7 +221,8 @@ def main():
         # a SCALE record must never be produced over host-staged messages by accident
         if rank == 0:
             sys.stderr.write("bench.py: the RCCL communicator could not be formed on every rank; refusing to fall back to host-staged "
-                             "gloo messages (pass --allow-host-staged for a functional rehearsal)\n")
+                             "gloo messages (pass --allow-host-staged for a functional rehearsal).  The ranks that did reach ncclCommInitRank wait for this one: "
+                             "the launcher (torch.distributed.run) ends them when this rank exits non-zero.\n")
         sys.exit(3)
 
     if world > 1 or loopback:
@@ -252,9 +273,13 @@ def main():
 
     def max_over_ranks(seconds):
         if transport is not None:
-            us = ctypes.c_int(int(seconds * 1e6))
-            transport.allreduce(transport.ctx, ctypes.cast(ctypes.byref(us), ctypes.c_void_p), 1, 2)
-            return us.value * 1e-6
+            # MAX of a non-negative double through the integer MAX reduction: the bit pattern of an IEEE double >= 0 orders as its value does
+            # (the transport's dtype 1 is a SUM; two 32-bit halves, high word decided first, would need two rounds)
+            hi = ctypes.c_int(int(seconds))                                      # whole seconds
+            transport.allreduce(transport.ctx, ctypes.cast(ctypes.byref(hi), ctypes.c_void_p), 1, 2)
+            lo = ctypes.c_int(int((seconds - int(seconds)) * 1e9) if int(seconds) == hi.value else -1)      # nanoseconds of the ranks that hold the largest second
+            transport.allreduce(transport.ctx, ctypes.cast(ctypes.byref(lo), ctypes.c_void_p), 1, 2)
+            return hi.value + lo.value * 1e-9
         if dist is not None:
             import torch
             t = torch.tensor([seconds], dtype=torch.float64)
@@ -262,14 +287,17 @@ def main():
             return float(t[0])
         return seconds
 
-    def measure(pot, meth, steps, warmup, nx=None, mem=False):
-        """One Simulation of `pot`/`meth`: W untimed steps, then exactly K steps between barrier + device syncs."""
+    def measure(pot, meth, steps, warmup, nx=None, mem=False, handshake=False):
+        """One Simulation of `pot`/`meth`: W untimed steps, then exactly K steps between barrier + device syncs.
+        handshake: exact message sizes are swapped before every exchange (COMD_HALO_HANDSHAKE=1) -- the cross-check of the sized protocol."""
         nx = nx or a.nx
         pairlist = meth == "cta_cell_pairlist"                # the reference's -L: pairlist bits for the CTA-per-cell LJ kernel
         args = ["-x", nx * px, "-y", nx * py, "-z", nx * pz, "-i", px, "-j", py, "-k", pz,
                 "-m", "cta_cell" if pairlist else meth, "-a", use_async] + (["-e"] if pot == "eam" else []) + (["-L"] if pairlist else [])
         free0 = pkg.device_mem_info()[0] if mem else 0
+        pkg.lib_host().comdSetHaloHandshake(1 if handshake else -1)
         sim = pkg.Simulation(args)
+        e0 = sim.energy()
         free1 = pkg.device_mem_info()[0] if mem else 0
 
         def sync_all():
@@ -293,7 +321,7 @@ def main():
         sim.sum_atoms()
         assert sim.energy()[2] == n_global, "atoms were lost"
         res = {"elapsed": elapsed, "force_ms": force_ms, "aux_ms": aux_ms, "launches": n_launch, "ep": ep, "ek": ek, "n_global": n_global,
-               "cap": sim.max_atoms, "nl_builds": sim.nl_builds - builds0,
+               "cap": sim.max_atoms, "nl_builds": sim.nl_builds - builds0, "e_initial": e0[0] + e0[1], "path": sim.force_path_info(),
                "mem_GB": {"simulation": (free0 - free1) / 1e9, "allocated_by_the_first_steps": (free1 - free2) / 1e9} if mem else None}
         sim.close()
         return res
@@ -317,14 +345,33 @@ def main():
                        **({"transport": transport_name or ("rccl-loopback" if loopback else "rccl")} if a.gpus > 1 or loopback else {})},
             "per_gpu_value": value / a.gpus,
             "energy_per_atom_eV": (ep + ek) / n_global,
+            "eFinal_over_eInitial": (ep + ek) / m["e_initial"],      # CoMD.c:413-440 "Simulation Validation": energy conservation over warm-up + timed steps
+            "force_path": m["path"],                                  # what the device library decided (candidate lists in use, brick image, list format, fall-backs)
             "roofline": roof,
         }
+        out["config"]["energy_reductions_timed"] = 1                  # the K steps are ONE timestep() call: one energy reduction (27 us) where the reference's loop does one per printRate = 10 steps
         if method == "thread_atom_nl":
             out["config"]["neighbor_list_builds_timed"] = m["nl_builds"]
         if rccl_info:
             out["config"].update(rccl_info)
         if transport_name:                                  # host-staged rehearsal: not an xGMI measurement
             out["measured"] = False
+    # N > 1 (and the one-GPU loopback rehearsal): the halo messages of the timed run were sized WITHOUT a handshake, from the counts both ends hold of the same
+    # message one step earlier.  Run the same W + K steps again from the same initial state with exact sizes swapped before every exchange: runs are
+    # bit-reproducible, so the two must agree to the last bit -- a mis-paired same-peer message (decomposition.c:57-66: two ranks on an axis make both
+    # neighbours of a phase ONE peer) or a truncated one cannot.
+    mismatch = False
+    if (a.gpus > 1 or loopback) and transport is not None:
+        # (COMD_BENCH_SELFTEST_PERTURB=1, tests only: the second run takes one step more, so that the comparison can be seen to fail)
+        c = measure(a.pot, method, a.steps + (1 if os.environ.get("COMD_BENCH_SELFTEST_PERTURB") == "1" else 0), a.warmup, handshake=True)
+        pkg.lib_host().comdSetHaloHandshake(-1)
+        same = ctypes.c_int(0 if (c["ep"], c["ek"], c["n_global"]) == (ep, ek, n_global) else 1)
+        transport.allreduce(transport.ctx, ctypes.cast(ctypes.byref(same), ctypes.c_void_p), 1, 2)      # (the energies are global sums: every rank holds the same pair)
+        mismatch = same.value != 0
+        if rank == 0:
+            out["sized_matches_handshake"] = not mismatch
+            out["handshake_run"] = {"ms_per_step": 1e3 * c["elapsed"] / a.steps, "energy_per_atom_eV": (c["ep"] + c["ek"]) / c["n_global"],
+                                    "dE_pot_eV": c["ep"] - ep, "dE_kin_eV": c["ek"] - ek, "d_atoms": c["n_global"] - n_global}
     # the other force methods on the same workload (one GPU only): not the headline, reported beside it
     variants = []
     if a.gpus == 1 and not a.no_variants:
@@ -363,11 +410,13 @@ def main():
             target = {"workload": "LJ Cu FCC 256^3, thread_atom", "skipped": f"{free / 1e9:.0f} GB of device memory free, the leg needs ~45 GB (atoms 16 GB, candidate lists 17 GB, packed positions 6 GB) and asks for 60"}
         else:
             try:
-                t = measure("lj", "thread_atom", 3, 1, nx=256, mem=True)
-                ms = 1e3 * t["elapsed"] / 3
-                roof = roofline_object("lj", "thread_atom", 256, t["n_global"], t["force_ms"] / 3, t["aux_ms"] / 3, "double")
-                target = {"workload": f"LJ Cu FCC 256^3 ({t['n_global']} atoms), thread_atom, fp64, 3 timed steps after 1", "value": t["n_global"] * 3 / t["elapsed"],
-                          "unit": "atom-updates/s", "ms_per_step": ms, "kernel_ms_per_step": t["force_ms"] / 3, "force_evaluation_ms": (t["force_ms"] + t["aux_ms"]) / 3,
+                TS = 10
+                t = measure("lj", "thread_atom", TS, 2, nx=256, mem=True)
+                ms = 1e3 * t["elapsed"] / TS
+                roof = roofline_object("lj", "thread_atom", 256, t["n_global"], t["force_ms"] / TS, t["aux_ms"] / TS, "double")
+                target = {"workload": f"LJ Cu FCC 256^3 ({t['n_global']} atoms), thread_atom, fp64, {TS} timed steps after 2", "value": t["n_global"] * TS / t["elapsed"],
+                          "unit": "atom-updates/s", "ms_per_step": ms, "kernel_ms_per_step": t["force_ms"] / TS, "force_evaluation_ms": (t["force_ms"] + t["aux_ms"]) / TS,
+                          "lj_candidate_lists_active": t["path"]["lj_candidate_lists_active"],
                           "hbm_frac": roof["frac"], "fp64_vector_frac": roof["fp64_vector"]["frac"], "energy_per_atom_eV": (t["ep"] + t["ek"]) / t["n_global"],
                           "device_memory_GB": t["mem_GB"], "note": "north_star asks for >= 50 % of the HBM roof on this line; a 5-sigma fp64 stencil is VALU-bound near 7 % (SURVEY.md 0.10, DESIGN.md 3)"}
             except Exception as exc:
@@ -387,6 +436,10 @@ def main():
         dist.barrier()
         hip.comdCommFinalize()
         dist.destroy_process_group()
+    if mismatch:
+        sys.stderr.write("bench.py: the run with sized halo messages and the run with the size handshake DISAGREE (sized_matches_handshake: false): "
+                         "the line above is not a valid measurement\n")
+        sys.exit(4)
 
 
 if __name__ == "__main__":

@@ -292,6 +292,16 @@ class Simulation:
         ms = lib_hip().comdForceTimingAuxMs(ctypes.c_void_p(self.lib.comdSimGpu(self.ptr)), ctypes.byref(n))
         return ms, int(n.value)
 
+    def force_path_info(self):
+        """What the force wrappers decided: LJ candidate lists in use, records of the EAM brick image, Verlet-list format, bricks in the thread-per-atom fall-back."""
+        hip = lib_hip()
+        gpu = ctypes.c_void_p(self.lib.comdSimGpu(self.ptr))
+        a, b = (ctypes.c_int * 4)(), (ctypes.c_int * 3)()
+        hip.comdForcePathInfo(gpu, a)
+        hip.comdEamBrickStats(gpu, b)
+        return {"lj_candidate_lists_active": bool(a[0]), "eam_brick_image_records": a[1], "neighbor_list_format": a[2], "eam_brick_cells": a[3],
+                "eam_bricks_in_thread_per_atom_fallback": b[0], "eam_bricks_per_launch": b[1]}
+
     # --- results ---
     def energy(self):
         """(ePotential, eKinetic, nGlobal) totals in eV."""

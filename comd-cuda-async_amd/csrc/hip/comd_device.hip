@@ -979,13 +979,16 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
       int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
       if (rows < 32) rows = 32;
       if (rows > 256) rows = 256;
-      if (!sim->eam_pot.pairRows) {                             // rows pass 1 leaves for pass 3: [slot][lane of the atom][trip] words
+      const int lanesMin = (rows + 15) / 16, roundAtoms = 64 / lanesMin < 16 ? 64 / lanesMin : 16;      // (as the kernel derives them from `rows`)
+      const int rounds = (sim->maxAtoms + roundAtoms - 1) / roundAtoms;
+      if (!sim->eam_pot.pairRows) {                             // rows pass 1 leaves for pass 3: per (cell, round) [2 quads][64 lanes] 16-byte elements
          const size_t slotsLocal = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms;
-         sim->eam_pot.pairRows = dalloc<unsigned>(slotsLocal * EAM_ROW_WORDS, false);
+         sim->eam_pot.pairRows = dalloc<unsigned>((size_t)sim->boxes.nLocalBoxes * rounds * 2 * 64 * 4, false);
          sim->eam_pot.pairRowCount = dalloc<unsigned short>(slotsLocal, false);      // (written by pass 1 before pass 3 reads it; no zeroing that could race with that)
          sim->eam_pot.pairRowLen = rows;
       }
       b.rows = sim->eam_pot.pairRowLen; b.rowsG = sim->eam_pot.pairRows; b.rowCountG = sim->eam_pot.pairRowCount;
+      b.listRounds = rounds; b.listQuads = 2;
       if (!sim->eam_pot.brickSel) {      // (zeroed on the launch stream, like the cell marks below)
          sim->eam_pot.brickSel = dalloc<unsigned long long>((size_t)sim->boxes.nLocalBoxes, false);
          HIP_CHECK(hipMemsetAsync(sim->eam_pot.brickSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(unsigned long long), st));
@@ -1060,6 +1063,16 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    }
 #undef COMD_LAUNCH_EAM_BRICK
    LAUNCH_CHECK();
+}
+
+// what the force wrappers decided for this simulation (bench.py records it beside the numbers): {LJ thread_atom candidate lists in use (0: the 27-cell walk),
+// records of the EAM brick image, Verlet-list format (comd_hip.h slabFormat), cells per EAM brick}
+extern "C" void comdForcePathInfo(SimGpu* sim, int out[4])
+{
+   out[0] = sim->lj_pot.packedCap > 0 ? 1 : 0;
+   out[1] = sim->eam_pot.brickImageCap;
+   out[2] = sim->atoms.neighborList.slabFormat;
+   out[3] = sim->eam_pot.brickBy * sim->eam_pot.brickBz;
 }
 
 extern "C" void comdEamBrickStats(SimGpu* sim, int out[3])

@@ -40,15 +40,14 @@ struct EamBrickArgs {
    int nby, nbz;                          // bricks along y and z
    int imageCap;                          // records the LDS image holds
    int rows;                              // neighbours a row holds (multiple of 8, <= 256)
-   unsigned* rowsG;                       // [local slots][EAM_ROW_WORDS] words of two image numbers, laid out [lane of the atom][trip], pass 1 -> pass 3
+   unsigned* rowsG;                       // [cell][listRounds][listQuads][64 lanes] uint4: words of two image numbers, a lane's words 4 j .. 4 j + 3 in quad j (pass 1 -> pass 3; Verlet rows)
    unsigned short* rowCountG;             // [local slots]
    const int* sel; int tag;               // cell selection: NULL = every local cell, else the cells with sel[c] == tag
    const int* brickList;                  // NULL: workgroup w takes brick w; else brick brickList[w] (the bricks of one group of the overlap mode, every cell selected)
    int fuseEmbed;
    int* status;
    int debug;                             // experiments (COMD_EAM_ABLATE): 1 no build sweeps, 2 no pair evaluation
-   // listed launches (Verlet lists): rowsG = [cell][listRounds][listQuads][64 lanes] uint4, rowCountG = [local slots] list lengths
-   int listRounds, listQuads;             // rounds of roundAtoms atoms a cell's capacity makes; 16-byte quads per lane and round (<= 3)
+   int listRounds, listQuads;             // rounds of roundAtoms atoms a cell's capacity makes; 16-byte quads per lane and round (2 without lists, <= 3 with)
    real_t rBuild2;                        // STEP 0: (cutoff + skin)^2
    int* stats;                            // [0] longest list (STEP 0), [1] bricks whose block outgrew the image, counted by STEP 0 / pass 1 (NULL: not counted)
    unsigned long long* brickSel;          // not listed: [local cells] the selection of its brick pass 1 wrote the cell's rows under; pass 3 must stage for the same (status[3] |= 4)
@@ -307,9 +306,8 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
       q = lane - ia * L;
    };
    // A ROW of n entries is dealt to the atom's L lanes in pairs: pair p = entries 2p, 2p+1 goes to lane p % L as its word p / L (trip).
-   //   not listed: in memory a lane's words are contiguous -- [slot][lane q][8 words] -- so pass 3 asks for them with two 16-byte loads, the row length
-   //               beside them, before it knows the length;
-   //   listed:     per (cell, round) [quad][64 lanes] 16-byte elements, a lane's words 4 j .. 4 j + 3 in quad j.
+   // In memory, per (cell, round): [quad][64 lanes] 16-byte elements, a lane's words 4 j .. 4 j + 3 in quad j; pass 3 asks for its quads and the row length
+   // together, before it knows the length.
    struct Pre3 { uint4 lo, hi, ex; int n; real_t f0x, f0y, f0z; };
    auto fetch3 = [&](const int iBox, const int ni, const int i0, Pre3& p) {
       int nRound, L, ia, q; roundOf(ni, i0, nRound, L, ia, q);
@@ -318,15 +316,13 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          const size_t cellSlot = (size_t)iBox * a.cap;
          const unsigned ii = (unsigned)(i0 + ia);
          p.n = (b.rowCountG + cellSlot)[ii];
+         const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
+         p.lo = src[0];
          if (LISTED) {
-            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
-            p.lo = src[0];
             if (b.listQuads > 1) p.hi = src[64];
             if (b.listQuads > 2) p.ex = src[128];
-         } else {
-            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG + cellSlot * EAM_ROW_WORDS);
-            p.lo = src[ii * (EAM_ROW_WORDS / 4) + 2u * q]; p.hi = src[ii * (EAM_ROW_WORDS / 4) + 2u * q + 1u];
-         }
+         } else if (L <= 5) p.hi = src[64];      // rows of pass 1: the second quad is asked for with the first when the atoms of the round have few lanes each (a lane's fifth
+                                                 // word exists from 8 L + 1 neighbours on); with six lanes or more it is fetched later, if a row turns out that long
          // pass 3 adds to the forces of pass 1: ask for them now, a whole cell of arithmetic before they are needed
          if (STEP == 3 && q == 0) { p.f0x = (a.fx + cellSlot)[ii]; p.f0y = (a.fy + cellSlot)[ii]; p.f0z = (a.fz + cellSlot)[ii]; }
       }
@@ -438,6 +434,10 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          if (n > b.rows) { over = true; n = b.rows; }
          if (b.debug & 2) n = 0;
          const int nPairs = (n + 1) >> 1;
+         if (!LISTED && STEP == 3 && L > 5 && __builtin_amdgcn_ballot_w64(4 * L + q < nPairs) != 0ull) {      // a long row in a round of few atoms: blocking
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
+            if (4 * L + q < nPairs) cur.hi = src[64];
+         }
          const unsigned short* __restrict__ myRow = sHit + (have ? ia : 0) * strideL;
          unsigned wReg[12] = { cur.lo.x, cur.lo.y, cur.lo.z, cur.lo.w, cur.hi.x, cur.hi.y, cur.hi.z, cur.hi.w, cur.ex.x, cur.ex.y, cur.ex.z, cur.ex.w };
 
@@ -554,10 +554,12 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          }
          if (BUILDS) {
             // hand the lane's words to pass 3 (the second 16 bytes only when a trip beyond the fourth was made), and the row lengths
+            // ([round 4] per (cell, round) [quad][64 lanes] 16-byte elements, as the Verlet rows: a round's first quads are one dense KB -- whole lines written
+            // and read -- where a [slot][16 lanes][8 words] block per atom left 32-byte sectors half used and 2.4 GB allocated at 80^3)
             if (have) {
-               uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG + cellSlot * EAM_ROW_WORDS) + ii * (EAM_ROW_WORDS / 4) + 2u * (unsigned)q;
+               uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
                if (q < nPairs) dst[0] = make_uint4(wReg[0], wReg[1], wReg[2], wReg[3]);
-               if (4 * L + q < nPairs) dst[1] = make_uint4(wReg[4], wReg[5], wReg[6], wReg[7]);
+               if (4 * L + q < nPairs) dst[64] = make_uint4(wReg[4], wReg[5], wReg[6], wReg[7]);
             }
             if (lane < nRound) (b.rowCountG + cellSlot)[(unsigned)(i0 + lane)] = (unsigned short)(sCnt[lane] < b.rows ? sCnt[lane] : b.rows);
          }

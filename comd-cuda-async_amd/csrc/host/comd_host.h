@@ -243,6 +243,7 @@ void preparePositionExchange(HaloExchange* positionExchange, struct SimFlatSt* s
 void destroyHaloExchange(HaloExchange** haloExchange);
 void invalidateHaloSizes(HaloExchange* haloExchange);      /* the next exchange of every axis swaps exact sizes again */
 void haloExchange(HaloExchange* haloExchange, void* data);
+void comdSetHaloHandshake(int on);                          /* 1: swap exact message sizes before every exchange (COMD_HALO_HANDSHAKE=1), 0: sized protocol, -1: ask the environment */
 int  haloMirrorFirstAxis(const HaloExchange* hh);         /* first axis of the self-neighbour tail the plugin mirrors directly; 3 = none */
 void exchangeData(HaloExchange* haloExchange, void* data, int iAxis);
 void prepareForceExchange(HaloExchange* forceExchange, struct SimFlatSt* sim);   /* one batched scan of all twelve cell lists */

@@ -540,12 +540,14 @@ void prepareForceExchange(HaloExchange* hh, SimFlat* sim)
 /* ---- driver -------------------------------------------------------------------------------------------------- */
 void invalidateHaloSizes(HaloExchange* hh) { for (int a = 0; a < 3; ++a) { hh->spec[a].valid = 0; hh->spec[a].haveBound = 0; } }
 
+static int handshakeCached = -1;
 static int handshakeForced(void)
 {
-   static int cached = -1;
-   if (cached < 0) { const char* e = getenv("COMD_HALO_HANDSHAKE"); cached = e && atoi(e) != 0; }
-   return cached;
+   if (handshakeCached < 0) { const char* e = getenv("COMD_HALO_HANDSHAKE"); handshakeCached = e && atoi(e) != 0; }
+   return handshakeCached;
 }
+/* bench.py's self-check: the same steps again with exact sizes swapped before every exchange, in the same process (1 on, 0 off, -1 back to the environment) */
+void comdSetHaloHandshake(int on) { handshakeCached = on; }
 
 /* transfer size both ends derive from last step's count: + 12.5 % + 64 atoms.  COMD_HALO_SLACK="percent,atoms" replaces the two numbers
  * (the tests set 0,0 to see a message outgrow its bound and the run stop) */

@@ -85,7 +85,7 @@ typedef struct EamPotentialGpuSt {
    /* cta_cell: pass 1 leaves each atom's in-cutoff neighbours (16-bit numbers in the staging order of its cell's stencil) here and pass 3
     * reads them back instead of testing the stencil again; laid out the way pass 3's lanes consume them -- per atom [16 lanes][8 trips]
     * words of two numbers -- so that a lane fetches its share with two 16-byte loads; allocated by the first cta_cell launch */
-   unsigned* pairRows;                 /* device [nLocalBoxes*maxAtoms][128] */
+   unsigned* pairRows;                 /* device [nLocalBoxes][rounds of 16 atoms][2 quads][64 lanes] uint4 (round 3: [nLocalBoxes*maxAtoms][128] words; COMD_EAM_CTA=cell still uses that) */
    unsigned short* pairRowCount;       /* device [nLocalBoxes*maxAtoms] */
    int     pairRowLen;                 /* neighbours a row can hold (<= 256) */
    /* cta_cell, brick form (round 3, hip/eam_brick_kernels.h): the selection marks of launches that cover a cell list (the cells with
@@ -320,6 +320,9 @@ void eamForce3GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, 
  * comdEamBrickStats: {bricks that took the thread-per-atom fall-back since the last call (their block outgrew the LDS image), bricks per launch over all
  * cells, records the image holds}; a non-zero first number after a re-size means a density the image cannot hold. */
 void comdEamBrickStats(SimGpu* sim, int out[3]);
+/* what the force wrappers decided for this simulation: {LJ thread_atom candidate lists in use (0: the plain 27-cell walk -- lists did not fit the device memory),
+ * records of the EAM brick image, Verlet-list format (NeighborListGpu.slabFormat), cells per EAM brick} */
+void comdForcePathInfo(SimGpu* sim, int out[4]);
 /* updateNeighborsGpu[Async], gpu_kernels.cu:251-279: the reference materialises 27*MAXATOMS neighbour
  * offsets per cell for its cta_cell/warp_atom EAM kernels; ours gather from the cell table directly,
  * so these are no-ops kept for link compatibility. */

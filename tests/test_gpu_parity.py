@@ -165,6 +165,41 @@ def test_eam_overlap_mode_takes_whole_bricks(gpu, orc, monkeypatch, env):
         assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < TOL["eam_dfembed_abs"]
 
 
+def test_eam_pass_3_over_another_partition_than_pass_1_stops_the_run():
+    """The contract of the cta_cell passes (include/comd_hip.h): eamForce3Gpu[Async] must cover the cells with the partition of the eamForce1Gpu[Async] calls of
+    the same force evaluation -- the 16-bit numbers pass 1 leaves index the LDS image of a brick, and the image holds the stencils of the SELECTED cells only.
+    Pass 1 over all cells followed by pass 3 over a cell list would read wrong neighbours silently; pass 1 records the selection it staged every cell's brick
+    for, pass 3 compares, and the mismatch stops the run with a message (in a child process: the stop is exit(-1))."""
+    import subprocess
+    import sys
+    code = r'''
+import ctypes, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package()
+pkg.setup_gpu(0, 0, verbose=False); pkg.init_parallel(0, 1, None)
+hip = pkg.lib_hip()
+with pkg.Simulation(["-x", 12, "-y", 12, "-z", 12, "-e", "-m", "cta_cell", "-r", 0.1]) as sim:
+    gpu = ctypes.c_void_p(sim.lib.comdSimGpu(sim.ptr))
+    CTA_CELL = 4
+    hip.eamForce1Gpu.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    hip.eamForce3GpuAsync.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int]
+    hip.comdDeviceMalloc.restype = ctypes.c_void_p; hip.comdDeviceMalloc.argtypes = [ctypes.c_long]
+    hip.comdCheckStatus.argtypes = [ctypes.c_void_p, ctypes.c_char_p]
+    cells = np.arange(0, sim.n_local_boxes, 3, dtype=np.int32)                  # every third cell: bricks with some cells selected, some not
+    d = ctypes.c_void_p(hip.comdDeviceMalloc(cells.nbytes))
+    hip.comdMemcpyHtoD(d, cells.ctypes.data_as(ctypes.c_void_p), cells.nbytes)
+    hip.eamForce1Gpu(gpu, CTA_CELL, 0)                                          # pass 1: all cells in one launch
+    hip.comdCheckStatus(gpu, b"after pass 1"); print("pass 1 fine", flush=True)
+    hip.eamForce3GpuAsync(gpu, len(cells), d, CTA_CELL, None, 0)                # pass 3: a cell list
+    hip.comdCheckStatus(gpu, b"after pass 3"); print("NOT STOPPED", flush=True)
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, COMD_EAM_GROUPS="0"))
+    assert "pass 1 fine" in proc.stdout and "NOT STOPPED" not in proc.stdout, proc.stdout[-500:] + proc.stderr[-1500:]
+    assert proc.returncode != 0 and "another partition" in proc.stderr, proc.stderr[-1500:]
+
+
 def test_lj_wave_candidate_lists_do_not_lose_a_pair(gpu, monkeypatch):
     """The list build prunes in single precision on positions relative to the corner of the local domain, with a margin for that rounding
     (comd_device.hip ljBoxMarginsF); the force kernel decides every pair on the fp64 records.  With the lists and with the plain 27-cell

@@ -122,6 +122,23 @@ def test_bench_reports_what_rccl_saw_and_maps_one_copy_of_it():
     assert len(cfg["librccl"]) == 1 and len(cfg["libamdhip64"]) == 1, (cfg["librccl"], cfg["libamdhip64"])
     assert all(os.path.realpath(p).startswith("/opt/rocm") for p in cfg["librccl"] + cfg["libamdhip64"]) and cfg["one_rocm_runtime_on_every_rank"]
     assert "measured" not in line
+    # [round 4] the self-check of the sized halo protocol: the same steps again with the size handshake, bit for bit (CoMD.c:413-440 beside it)
+    assert line["sized_matches_handshake"] is True
+    assert line["handshake_run"]["dE_pot_eV"] == 0.0 and line["handshake_run"]["dE_kin_eV"] == 0.0 and line["handshake_run"]["d_atoms"] == 0
+    assert abs(line["eFinal_over_eInitial"] - 1.0) < 1e-4
+
+
+@pytest.mark.gpu
+def test_bench_self_check_catches_a_run_that_differs(tmp_path):
+    """The comparison is live: when the second run is made to differ (COMD_BENCH_SELFTEST_PERTURB=1 gives it one time step more), bench.py says
+    sized_matches_handshake: false and exits non-zero."""
+    import json
+    env = dict(os.environ, COMD_LOOPBACK_TRANSPORT="1", MASTER_PORT=str(_free_port()), COMD_BENCH_SELFTEST_PERTURB="1")
+    proc = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--nx", "20", "--steps", "3", "--warmup", "1",
+                           "--no-variants", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 4, (proc.returncode, proc.stderr[-2000:])
+    line = json.loads(proc.stdout.strip().splitlines()[-1])
+    assert line["sized_matches_handshake"] is False
 
 
 def test_bench_refuses_to_run_many_ranks_without_rccl():
