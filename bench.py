@@ -137,7 +137,7 @@ def profiled(pot, method, nx):
         if rec:
             # a record made for another version of the kernel must not be divided by this run's time: profiles/rNN_summarize.py stores a hash of the kernel's
             # source header with every record; a record whose hash is not the current one is reported as stale, not used
-            if rec.get("kernel_source_sha16") and rec["kernel_source_sha16"] != kernel_source_hash(pot, method):
+            if rec.get("kernel_source_sha16") != kernel_source_hash(pot, method):      # (records of rounds 1-3 carry no hash: stale by definition)
                 return None, f"profiles/{name} (STALE: collected for another version of the kernel source; re-run profiles/r04_collect.sh)"
             return rec, f"profiles/{name}"
     return None, None

@@ -637,8 +637,25 @@ static void launchLjThreadAtom(SimGpu* sim, const LjArgs& a, int num_cells, int*
                  g_rank, listBytes / 1e9, (double)freeB / 1e9);
          lj->packedCap = -1;
       } else {
-         lj->waveCand = dalloc<unsigned>((size_t)sim->boxes.nLocalBoxes * lj->waveCandWaves * lj->waveCandCap, false);
-         lj->waveCandCount = dalloc<int>((size_t)sim->boxes.nLocalBoxes * lj->waveCandWaves * 2, false);
+         // Everything the lists need is allocated HERE, and a refusal is not fatal: ranks that share a device can all see the memory free and then not all
+         // get it -- whoever is refused runs the plain walk, and says so (bench.py records force_path.lj_candidate_lists_active).
+         auto tryAlloc = [](size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) { (void)hipGetLastError(); p = nullptr; } return p; };
+         const size_t recs = (size_t)sim->boxes.nTotalBoxes * lj->packedCap * 4;
+         lj->waveCand = (unsigned*)tryAlloc((size_t)sim->boxes.nLocalBoxes * lj->waveCandWaves * lj->waveCandCap * sizeof(unsigned));
+         lj->waveCandCount = (int*)tryAlloc((size_t)sim->boxes.nLocalBoxes * lj->waveCandWaves * 2 * sizeof(int));
+         bool ok = lj->waveCand && lj->waveCandCount;
+         for (int k = 0; k < (sim->interior_stream ? 2 : 1) && ok; ++k) {
+            lj->packedR[k] = (real_t*)tryAlloc(recs * sizeof(real_t));
+            lj->packedF[k] = (float*)tryAlloc(recs * sizeof(float));
+            ok = lj->packedR[k] && lj->packedF[k];
+         }
+         if (!ok) {
+            void* ps[6] = { lj->waveCand, lj->waveCandCount, lj->packedR[0], lj->packedF[0], lj->packedR[1], lj->packedF[1] };
+            for (void* q : ps) if (q) (void)hipFree(q);
+            lj->waveCand = nullptr; lj->waveCandCount = nullptr; lj->packedR[0] = lj->packedR[1] = nullptr; lj->packedF[0] = lj->packedF[1] = nullptr;
+            fprintf(stderr, "Rank %d: the device refused the %.1f GB of the LJ candidate lists: running without them (the plain 27-cell walk, ~1.4x slower)\n", g_rank, listBytes / 1e9);
+            lj->packedCap = -1;
+         }
       }
    }
    const bool prune = pruneEnv && lj->waveCand;
@@ -1064,6 +1081,9 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
 #undef COMD_LAUNCH_EAM_BRICK
    LAUNCH_CHECK();
 }
+
+// cta_cell: size the brick image again at the next launch (between two force evaluations only: pass 1 and pass 3 of one evaluation must stage alike)
+extern "C" void comdEamBrickResize(SimGpu* sim) { sim->eam_pot.brickImageCap = 0; }
 
 // what the force wrappers decided for this simulation (bench.py records it beside the numbers): {LJ thread_atom candidate lists in use (0: the 27-cell walk),
 // records of the EAM brick image, Verlet-list format (comd_hip.h slabFormat), cells per EAM brick}

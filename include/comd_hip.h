@@ -320,6 +320,8 @@ void eamForce3GpuAsync(SimGpu* sim, int num_cells, int* cells_list, int method, 
  * comdEamBrickStats: {bricks that took the thread-per-atom fall-back since the last call (their block outgrew the LDS image), bricks per launch over all
  * cells, records the image holds}; a non-zero first number after a re-size means a density the image cannot hold. */
 void comdEamBrickStats(SimGpu* sim, int out[3]);
+/* cta_cell: have the next launch read the occupancies again and size the image for the fullest block (call between force evaluations) */
+void comdEamBrickResize(SimGpu* sim);
 /* what the force wrappers decided for this simulation: {LJ thread_atom candidate lists in use (0: the plain 27-cell walk -- lists did not fit the device memory),
  * records of the EAM brick image, Verlet-list format (NeighborListGpu.slabFormat), cells per EAM brick} */
 void comdForcePathInfo(SimGpu* sim, int out[4]);

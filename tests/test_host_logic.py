@@ -200,3 +200,32 @@ def test_hilbert_numbering_is_a_bijection_and_local(pkg, n, eam):
                 assert sim.box_from_coord((c["rx"][b, i], c["ry"][b, i], c["rz"][b, i])) == b
     assert plain.cells()["nAtoms"][:plain.n_local_boxes].sum() == hil.cells()["nAtoms"][:hil.n_local_boxes].sum()
     plain.close(); hil.close()
+
+
+def test_bench_never_divides_a_stale_pmc_record_by_a_live_time(tmp_path, monkeypatch):
+    """bench.py's `traffic` and `valu_issue_frac` are stored rocprofv3 PMC counts divided by this run's kernel time.  A record is valid for ONE version of the
+    kernel source: profiles/rNN_summarize.py stores a hash of the kernel's header with it, bench.profiled() refuses a record whose hash is not the tree's
+    (and says so in the provenance string), and `profiles/r04_summarize.py --check` lists stale records."""
+    import importlib
+    import json
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    good = bench.kernel_source_hash("eam", "cta_cell")
+    assert len(good) == 16 and good == bench.kernel_source_hash("eam", "thread_atom_nl") != bench.kernel_source_hash("lj", "thread_atom")
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    monkeypatch.setattr(bench, "kernel_source_hash", lambda pot, method: good)
+    (prof / "r04_traffic.json").write_text(json.dumps({"eam/cta_cell/80": {"fetch_KiB": 1.0, "write_KiB": 2.0, "kernel_source_sha16": good},
+                                                       "lj/thread_atom/80": {"fetch_KiB": 1.0, "write_KiB": 2.0, "kernel_source_sha16": "0" * 16}}))
+    (prof / "r03_traffic.json").write_text(json.dumps({"lj/thread_atom_nl/80": {"fetch_KiB": 1.0, "write_KiB": 2.0}}))
+    rec, prov = bench.profiled("eam", "cta_cell", 80)
+    assert rec and prov == "profiles/r04_traffic.json"
+    rec, prov = bench.profiled("lj", "thread_atom", 80)
+    assert rec is None and "STALE" in prov
+    rec, prov = bench.profiled("lj", "thread_atom_nl", 80)                     # a record without a hash (rounds 1-3) is stale by definition
+    assert rec is None and "STALE" in prov
+    assert bench.profiled("eam", "thread_atom", 80) == (None, None)
