@@ -30,6 +30,9 @@
 // which cells a launch selects) plus one record FAR_AWAY that pads odd rows.
 #define EAM_BRICK_MAX_CELLS 128           // cells of the staged block: 3 * (BY + 2) * (BZ + 2) <= 128
 #define EAM_BRICK_SR 6                    // records a lane keeps in registers during the build (384 per wave; larger stencils read the LDS)
+#ifndef EAM_BRICK_SR_BUILD
+#define EAM_BRICK_SR_BUILD 6              // ... during a Verlet-row build (cells of cutoff + skin: 371 records in a stencil on average at 80^3)
+#endif
 #define EAM_BRICK_STAGE 8                 // staging iterations with all loads in flight (256 threads x 8 = 128 cells x 16 slots)
 #define EAM_BRICK_STAGE_LISTED 10         // listed launches stage 32 slots per cell (cells of cutoff + skin hold 14 atoms on average): 256 x 10 = 80 cells x 32 slots
 #define EAM_LIST_WORDS 12                 // words (two 16-bit numbers each) a lane holds of a listed row: 3 quads
@@ -104,7 +107,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
    static_assert(STEP != 0 || LISTED, "STEP 0 builds Verlet rows");
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int REC = 3;                                    // doubles per staged atom: x, y, z (24-byte stride); pass 3 keeps F' in an array of its own
-   constexpr int SR = EAM_BRICK_SR;
+   constexpr int SR = (STEP == 0) ? EAM_BRICK_SR_BUILD : EAM_BRICK_SR;
    constexpr bool BUILDS = LISTED ? STEP == 0 : STEP == 1;   // this launch sweeps the stencil for rows
    constexpr int SLOT_BITS = LISTED ? 5 : 4, SLOTS = 1 << SLOT_BITS;      // slots of a cell requested before its occupancy is known
    constexpr int STAGE = LISTED ? EAM_BRICK_STAGE_LISTED : EAM_BRICK_STAGE;
@@ -422,7 +425,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          int n = 0;
          if (BUILDS) {
             if (i0 != 0) {                                   // (round 0 was built above)
-               const int rec[SR] = { 0, 0, 0, 0, 0, 0 }; const real_t v0[SR] = { R(0.0), R(0.0), R(0.0), R(0.0), R(0.0), R(0.0) };
+               const int rec[SR] = { 0 }; const real_t v0[SR] = { R(0.0) };
                __builtin_amdgcn_wave_barrier();
                buildRound(i0, false, rec, v0, v0, v0);
             }

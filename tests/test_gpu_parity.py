@@ -236,17 +236,29 @@ def test_reference_recorded_forces(gpu, case, method):
 # ---------------------------------------------------------------- energy traces
 @pytest.mark.parametrize("method", METHODS)
 @pytest.mark.parametrize("case", ["lj_20", "eam_20"])
-def test_energy_trace_matches_reference(gpu, case, method):
+def test_energy_trace_matches_reference(gpu, orc, case, method):
+    """BASELINE configs[0] (20^3, 100 steps).  Two checkers side by side: the ORACLE stepped through the same 100 steps (the pinned one: oracle/comd_oracle.c
+    is held to the reference-held energies and to the reference's own TUs, tests/test_oracle_golden.py) -- potential and kinetic energy per atom at steps
+    10, 50 and 100 -- and the `survey_recorded` trace (recorded by the survey stage from a stand-in-header build: a secondary cross-check that pins nothing)."""
     ref = S[case]
     with gpu.Simulation(_args(ref["nx"], ref["eam"], 0.0, method)) as sim:
+        o = orc.Oracle(ref["nx"], eam=ref["eam"], cap=max(sim.max_atoms, 64))
+        n = sim.n_global
         e, u, _ = _per_atom(sim)
+        assert abs(u - o.energy()[0] / n) < TOL["energy_per_atom_step0"]
         assert abs(u - ref["step0"]["U"]) < TOL["energy_per_atom_step0"]
         assert abs(e - ref["step0"]["E"]) < TOL["energy_per_atom_step0"]
         done = 0
         for step in (10, 50, 100):
             sim.step(step - done)
+            o.step(step - done)
             done = step
-            assert abs(_per_atom(sim)[0] - ref["E_at"][str(step)]) < TOL["energy_per_atom_trace"], step
+            et, ut, kt = _per_atom(sim)
+            op, ok = o.energy()
+            assert abs(et - (op + ok) / n) < TOL["energy_per_atom_trace"], (step, et - (op + ok) / n)
+            # (U and K exchange energy: a round-off difference in a force moves both, opposite ways, ten times further than their sum)
+            assert abs(ut - op / n) < 10 * TOL["energy_per_atom_trace"] and abs(kt - ok / n) < 10 * TOL["energy_per_atom_trace"], (step, ut - op / n, kt - ok / n)
+            assert abs(et - ref["E_at"][str(step)]) < TOL["energy_per_atom_trace"], step
         e, u, k = _per_atom(sim)
         assert abs(u - ref["step100"]["U"]) < 5e-12
         sim.sum_atoms()
