@@ -1629,11 +1629,16 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
       } else
       {
          // one workgroup per cell, a thread per slot; the LDS holds a whole group of full cells (<= 9 * 512 atoms = 108 KB)
-         const size_t lds = (size_t)3 * NL_GROUP_CELLS * sim->maxAtoms * sizeof(real_t);
+         // COMD_NL_BANK_ORDER=1: rows ordered by LDS bank class (nl_kernels.h): 2 x 16 counters of 16 bits per thread behind the records.  An experiment that settled a
+         // question (profiles/r04_experiments/README.md): it takes 45 % of the bank-conflict cycles out of LJ_Force_nl_slabs and 1.3 % of its time -- the kernel is bound by
+         // VALU issue, not by the LDS -- while the build goes from 11 to 79 ms.  Off by default.
+         const int bankOrder = getenv("COMD_NL_BANK_ORDER") && atoi(getenv("COMD_NL_BANK_ORDER")) != 0;
+         const int groupCap = NL_GROUP_CELLS * sim->maxAtoms;
+         const size_t lds = (size_t)3 * groupCap * sizeof(real_t) + (bankOrder ? (size_t)2 * 16 * sim->maxAtoms * sizeof(unsigned short) : 0);
          allowDynamicLds((const void*)BuildNeighborListSlabs, lds);
          hipLaunchKernelGGL(BuildNeighborListSlabs, dim3(sim->boxes.nLocalBoxes), dim3(sim->maxAtoms), lds, st,
                             sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->boxes.nAtoms, sim->neighbor_cells,
-                            sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status);
+                            sim->boxes.nLocalBoxes, sim->maxAtoms, sv, rBuild * rBuild, n->lastR.x, n->lastR.y, n->lastR.z, n->stats, sim->status, bankOrder, groupCap);
       }
       LAUNCH_CHECK();
       int h[2];

@@ -233,7 +233,7 @@ __global__ __launch_bounds__(512)
 void BuildNeighborListSlabs(const real_t* __restrict__ rx, const real_t* __restrict__ ry, const real_t* __restrict__ rz,
                             const int* __restrict__ nAtoms, const int* __restrict__ nbr, int nCells, int cap,
                             NlSlabView nl, real_t rBuild2, real_t* __restrict__ lastX, real_t* __restrict__ lastY, real_t* __restrict__ lastZ,
-                            int* __restrict__ stats, int* __restrict__ status)
+                            int* __restrict__ stats, int* __restrict__ status, int bankOrder, int groupCap)
 {
    extern __shared__ __attribute__((aligned(16))) real_t ldsPos[];
    real_t* __restrict__ sp = ldsPos;
@@ -269,7 +269,7 @@ void BuildNeighborListSlabs(const real_t* __restrict__ rx, const real_t* __restr
       }
       if (i == 0) atomicMax(&stats[0], total);
       __syncthreads();
-      if (active) {
+      if (active && !bankOrder) {
          unsigned short* __restrict__ row = nl.list + ((size_t)(iBox * NL_GROUPS + g) * nl.rows) * cap + i;
          const int me = selfAt >= 0 ? selfAt + i : -1;
          int n = 0;
@@ -282,6 +282,49 @@ void BuildNeighborListSlabs(const real_t* __restrict__ rx, const real_t* __restr
          }
          if (n > nl.rows) { over = true; n = nl.rows; }
          nl.count[(size_t)(iBox * NL_GROUPS + g) * cap + i] = n;
+      }
+      if (bankOrder) {
+         // [round 4] The force kernel gathers entry k of 64 different rows with one ds_read_b64 per coordinate, and a row in record order sends neighbouring
+         // lanes to neighbouring records: SQ_LDS_BANK_CONFLICT was 53 % of the LDS cycles.  An entry e (= 3 t) names the 8-byte word e of the staging, so its
+         // bank pair is e mod 16: order every row so that entry k of lane i has class (i + k) mod 16 -- the 16 lanes of a quarter wave then read 16 different
+         // bank pairs at every step -- by dealing the row's entries round-robin over the classes, starting at class i mod 16 and skipping a class that has run
+         // out (the tail of a row loses the alignment; the classes of a row of 240 hold 15 +- 4).  Two sweeps over the records: count per class, then place.
+         unsigned short* sCnt = (unsigned short*)(sp + 3 * (size_t)groupCap);      // [16][blockDim]: hits of this lane per class
+         unsigned short* sRun = sCnt + 16 * blockDim.x;                            // [16][blockDim]: ... placed so far
+         for (int c = 0; c < 16; ++c) { sCnt[c * blockDim.x + i] = 0; sRun[c * blockDim.x + i] = 0; }
+         const int me = selfAt >= 0 ? selfAt + i : -1;
+         int n = 0;
+         if (active) {
+            for (int t = 0; t < total; ++t) {
+               const real_t dx = xi - sp[3 * t], dy = yi - sp[3 * t + 1], dz = zi - sp[3 * t + 2];
+               if (dx*dx + dy*dy + dz*dz <= rBuild2 && t != me) { ++sCnt[((3 * t) & 15) * blockDim.x + i]; ++n; }
+            }
+            if (n > nl.rows) over = true;
+            unsigned short* __restrict__ row = nl.list + ((size_t)(iBox * NL_GROUPS + g) * nl.rows) * cap + i;
+            int cnt[16];
+#pragma unroll
+            for (int c = 0; c < 16; ++c) cnt[c] = sCnt[c * blockDim.x + i];
+            const int s0 = i & 15;
+            for (int t = 0; t < total; ++t) {
+               const real_t dx = xi - sp[3 * t], dy = yi - sp[3 * t + 1], dz = zi - sp[3 * t + 2];
+               if (dx*dx + dy*dy + dz*dz <= rBuild2 && t != me) {
+                  const int c = (3 * t) & 15;
+                  const int m = sRun[c * blockDim.x + i]++;
+                  // entries dealt before the m-th of class c: every class c' contributes min(cnt[c'], m + 1) when it comes before c in the cycle that starts
+                  // at s0, min(cnt[c'], m) when it comes after
+                  const int rc_ = (c - s0) & 15;
+                  int pos = m;
+#pragma unroll
+                  for (int cc = 0; cc < 16; ++cc) {
+                     const int before = (((cc - s0) & 15) < rc_) ? 1 : 0;
+                     const int lim = m + before;
+                     pos += cc == c ? 0 : (cnt[cc] < lim ? cnt[cc] : lim);
+                  }
+                  if (pos < nl.rows) row[(size_t)pos * cap] = (unsigned short)(3 * t);
+               }
+            }
+            nl.count[(size_t)(iBox * NL_GROUPS + g) * cap + i] = n < nl.rows ? n : nl.rows;
+         }
       }
    }
    if (over) atomicOr(&status[3], 2);
