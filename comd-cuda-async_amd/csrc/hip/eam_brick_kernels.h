@@ -322,8 +322,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
          p.lo = src[0];
          if (LISTED) {
-            if (b.listQuads > 1) p.hi = src[64];
-            if (b.listQuads > 2) p.ex = src[128];
+            if (b.listQuads > 1) p.hi = src[64];      // (the third quad -- a lane's words 8 .. 11: rows beyond 16 L entries -- is fetched later, by the lanes that have such words)
          } else if (L <= 5) p.hi = src[64];      // rows of pass 1: the second quad is asked for with the first when the atoms of the round have few lanes each (a lane's fifth
                                                  // word exists from 8 L + 1 neighbours on); with six lanes or more it is fetched later, if a row turns out that long
          // pass 3 adds to the forces of pass 1: ask for them now, a whole cell of arithmetic before they are needed
@@ -437,6 +436,10 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
          if (n > b.rows) { over = true; n = b.rows; }
          if (b.debug & 2) n = 0;
          const int nPairs = (n + 1) >> 1;
+         if (LISTED && STEP != 0 && b.listQuads > 2 && __builtin_amdgcn_ballot_w64(8 * L + q < nPairs) != 0ull) {      // a row of more than 16 L entries: blocking
+            const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
+            if (8 * L + q < nPairs) cur.ex = src[128];
+         }
          if (!LISTED && STEP == 3 && L > 5 && __builtin_amdgcn_ballot_w64(4 * L + q < nPairs) != 0ull) {      // a long row in a round of few atoms: blocking
             const uint4* __restrict__ src = reinterpret_cast<const uint4*>(b.rowsG) + ((size_t)iBox * b.listRounds + (unsigned)(i0 / roundAtoms)) * b.listQuads * 64 + lane;
             if (4 * L + q < nPairs) cur.hi = src[64];
