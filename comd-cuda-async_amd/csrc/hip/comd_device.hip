@@ -329,7 +329,7 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
       }
       nl->lastR.x = dalloc<real_t>(localSlots); nl->lastR.y = dalloc<real_t>(localSlots); nl->lastR.z = dalloc<real_t>(localSlots);
       HIP_CHECK(hipHostMalloc((void**)&nl->updateRequiredHost, 64, hipHostMallocDefault));      // pinned: written by kernels, read by the host
-      *nl->updateRequiredHost = 0;
+      memset(nl->updateRequiredHost, 0, 64);
       HIP_CHECK(hipHostGetDevicePointer((void**)&nl->updateRequired, nl->updateRequiredHost, 0));
       nl->forceRebuildFlag = 1; nl->nBuilds = 0;
    }
@@ -341,6 +341,8 @@ extern "C" void AllocateGpu(SimGpu* sim, const GpuConfig* cfg)
    sim->reduceBlocks = 1024;
    sim->reduceBuf = dalloc<real_t>(2 * (size_t)sim->reduceBlocks + 2);
    HIP_CHECK(hipHostMalloc((void**)&sim->pinned, 64 * sizeof(real_t), hipHostMallocDefault));
+   memset(sim->pinned, 0, 64 * sizeof(real_t));
+   HIP_CHECK(hipHostGetDevicePointer((void**)&sim->statusMirrorDev, (int*)(sim->pinned + 32), 0));
 
    if (cfg->gpuAsync) {                         // gpu_utility.c:150-159
       hipStream_t bs, is;
@@ -478,6 +480,8 @@ extern "C" void DestroyGpu(SimGpu* sim)
    if (sim->statusEvent) (void)hipEventDestroy((hipEvent_t)sim->statusEvent);
    if (sim->pinned) HIP_CHECK(hipHostFree(sim->pinned));
    if (sim->atoms.neighborList.updateRequiredHost) HIP_CHECK(hipHostFree(sim->atoms.neighborList.updateRequiredHost));
+   if (sim->atoms.neighborList.brickStatsMirror) HIP_CHECK(hipHostFree(sim->atoms.neighborList.brickStatsMirror));
+   if (sim->atoms.neighborList.brickStatsEvent) (void)hipEventDestroy((hipEvent_t)sim->atoms.neighborList.brickStatsEvent);
    if (sim->boundary_stream) HIP_CHECK(hipStreamDestroy(S(sim->boundary_stream)));
    if (sim->interior_stream) HIP_CHECK(hipStreamDestroy(S(sim->interior_stream)));
    memset(sim, 0, sizeof(*sim));
@@ -511,6 +515,13 @@ extern "C" void comdCheckStatus(SimGpu* sim, const char* where)
 extern "C" void comdPollStatus(SimGpu* sim, comdStream_t stream, const char* where)
 {
    int* mirror = (int*)(sim->pinned + 32);               // four ints of the 64-real_t pinned block, away from the energy words
+   // [round 4] The fused drift kernels copy the status words into the mirror as they start (step_kernels.h skinProgress): nothing to enqueue here -- the separate
+   // 16-byte copy per step was a blit kernel with a launch gap on either side, 10 us of every step.  Without such a kernel since the last poll: the copy, as before.
+   if (sim->statusMirrored) {
+      sim->statusMirrored = 0;
+      if (mirror[0] | mirror[1] | mirror[2] | mirror[3]) comdCheckStatus(sim, where);
+      return;
+   }
    if (sim->statusEvent) {
       if (hipEventQuery((hipEvent_t)sim->statusEvent) != hipSuccess) return;       // the previous mirror has not landed yet: look again next step
       if (mirror[0] | mirror[1] | mirror[2] | mirror[3]) comdCheckStatus(sim, where);
@@ -941,6 +952,7 @@ static void eamBrickBuildLists(SimGpu* sim, hipStream_t st, int spline)
    if (cap > 4096) cap = 4096;
    { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) cap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force halves and the fall-back
    sim->eam_pot.brickImageCap = cap;
+   const int headroom = cap / 64 > 8 ? cap / 64 : 8;
    // the lists: [0, stride) bricks that hold a boundary cell, [stride, 2 stride) the others, [2 stride, 3 stride) all of them; brick order, halves adjacent
    std::vector<char> isBoundary((size_t)sim->boxes.nLocalBoxes, 0);
    for (int c : boundary) if (c >= 0 && c < sim->boxes.nLocalBoxes) isBoundary[c] = 1;
@@ -955,7 +967,9 @@ static void eamBrickBuildLists(SimGpu* sim, hipStream_t st, int spline)
       for (int dz = 0; dz < b.bz; ++dz) for (int dy = 0; dy < b.by; ++dy)
          if (by0 + dy < gy && bz0 + dz < gz) group[comdBoxFromTuple(&hg, x, by0 + dy, bz0 + dz)] = any ? 1 : 2;
       const int g = any ? 0 : 1;
-      const bool halves = whole[i] + 1 > cap && b.bz % 2 == 0 && bz0 + b.bz / 2 < gz;      // (an upper half outside the grid would be an empty workgroup)
+      // (a brick within 1.5 % of the image goes in halves too: the lists outlive this build -- atoms wander between cells from one build to the next -- and a brick
+      // that outgrows the image later takes the thread-per-atom form until the lists are made again)
+      const bool halves = whole[i] + 1 > cap - headroom && b.bz % 2 == 0 && bz0 + b.bz / 2 < gz;      // (an upper half outside the grid would be an empty workgroup)
       const int e[2] = { halves ? i | (1 << 28) : i, i | (2 << 28) };
       for (int k = 0; k < (halves ? 2 : 1); ++k) { lists[(size_t)g * stride + cnt[g]++] = e[k]; lists[(size_t)2 * stride + cnt[2]++] = e[k]; }
    }
@@ -1263,30 +1277,34 @@ extern "C" void advancePositionGpu(SimGpu* sim, real_t dt)
 static SkinCheck skinCheckOf(SimGpu* sim)
 {
    NeighborListGpu* n = &sim->atoms.neighborList;
-   SkinCheck sk = { nullptr, nullptr, nullptr, R(0.0), nullptr };
+   SkinCheck sk = { nullptr, nullptr, nullptr, R(0.0), R(0.0), nullptr, nullptr, nullptr, 0, sim->status, sim->statusMirrorDev };
+   sim->statusMirrored = 1;
    if (!n->lastR.x || n->nBuilds == 0 || n->forceRebuildFlag) return sk;
-   sk.lastX = n->lastR.x; sk.lastY = n->lastR.y; sk.lastZ = n->lastR.z; sk.skinHalf2 = n->skinDistanceHalf2; sk.flag = n->updateRequired;
+   sk.lastX = n->lastR.x; sk.lastY = n->lastR.y; sk.lastZ = n->lastR.z; sk.skinHalf2 = n->skinDistanceHalf2;
+   sk.softHalf2 = n->softHalf2 > R(0.0) ? n->softHalf2 : n->skinDistanceHalf2;
+   sk.hard = n->updateRequired + 1; sk.soft = n->updateRequired + 2; sk.progress = n->updateRequired + 3; sk.stamp = ++n->driftCount;
    n->checkFused = 1;
    return sk;
 }
-
 extern "C" void advanceVelocityPositionGpu(SimGpu* sim, real_t dtKick, real_t dtDrift)
 {
    const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
+   const SkinCheck sk = skinCheckOf(sim);
    hipLaunchKernelGGL(AdvanceVelocityPosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
                       sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.iSpecies, sim->species_mass,
-                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick, dtDrift, skinCheckOf(sim));
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick, dtDrift, sk);
    LAUNCH_CHECK();
 }
 
 extern "C" void advanceVelocityVelocityPositionGpu(SimGpu* sim, real_t dtKick1, real_t dtKick2, real_t dtDrift)
 {
    const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
+   const SkinCheck sk = skinCheckOf(sim);
    hipLaunchKernelGGL(AdvanceVelocityVelocityPosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
                       sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.iSpecies, sim->species_mass,
-                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick1, dtKick2, dtDrift, skinCheckOf(sim));
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick1, dtKick2, dtDrift, sk);
    LAUNCH_CHECK();
 }
 
@@ -1318,11 +1336,11 @@ static AtomArrays atomArrays(SimGpu* sim)
 
 static int sortBlock(int cap) { return ((cap + 63) / 64) * 64; }
 
-static void launchCompactSort(SimGpu* sim, int first, int nCells, hipStream_t st)
+static void launchCompactSort(SimGpu* sim, int first, int nCells, hipStream_t st, bool shortRuns = false)
 {
    if (nCells <= 0) return;
    // cells per wave / workgroup: the local cells are nearly all clean (one flag each), the halo cells were all just refilled
-   const bool halo = first >= sim->boxes.nLocalBoxes;
+   const bool halo = shortRuns || first >= sim->boxes.nLocalBoxes;
    if (sim->maxAtoms <= 64) {
       const int run = halo ? 2 : COMPACT_RUN_WAVE;
       hipLaunchKernelGGL(CompactSortCellsWave, dim3(ceilDiv(nCells, 4 * run)), dim3(256), 0, st,
@@ -1351,9 +1369,9 @@ extern "C" void buildAtomListGpu(SimGpu*, comdStream_t) {}
 
 extern "C" void sortAtomsGpu(SimGpu* sim, comdStream_t stream)
 {
-   // after the atom exchange: local cells that received atoms (few), then the halo cells (all of them)
-   launchCompactSort(sim, 0, sim->boxes.nLocalBoxes, S(stream));
-   launchCompactSort(sim, sim->boxes.nLocalBoxes, sim->boxes.nTotalBoxes - sim->boxes.nLocalBoxes, S(stream));
+   // after the atom exchange: local cells that received atoms (few) and the halo cells (all of them), one launch over all cells with the short runs of the halo
+   // cells (round 3: two launches; a clean local cell costs its wave one flag read)
+   launchCompactSort(sim, 0, sim->boxes.nTotalBoxes, S(stream), true);
 }
 
 // ---- halo pack / unpack ------------------------------------------------------------------------------------------------
@@ -1545,26 +1563,50 @@ extern "C" int neighborListUpdateRequiredGpu(SimGpu* sim)
    NeighborListGpu* n = &sim->atoms.neighborList;
    if ((!n->list && !n->list16 && !n->pairlist && !n->brickRows) || n->forceRebuildFlag) return 1;
    hipStream_t st = S(sim->boundary_stream);
-   // The flag lives in pinned host memory (the kernels write it there): a stream synchronisation and a host read, no copy.  It is raised only; the host
-   // clears it here, when nothing that writes it is in flight.
-   if (n->checkFused) {                                      // the drift kernel of the step checked the positions it wrote
+   // The flags live in pinned host memory (the kernels write them there): a stream synchronisation and a host read, no copy.
+   if (n->checkFused) {                                      // the drift kernel of the step checked the positions it wrote (step_kernels.h SkinCheck)
       n->checkFused = 0;
       HIP_CHECK(hipStreamSynchronize(st));
-   } else {
-      HIP_CHECK(hipStreamSynchronize(st));
-      *n->updateRequiredHost = 0;
-      hipLaunchKernelGGL(NeighborListUpdateRequired, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
-                         sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, n->lastR.x, n->lastR.y, n->lastR.z,
-                         sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, n->skinDistanceHalf2, n->updateRequired);
-      LAUNCH_CHECK();
-      HIP_CHECK(hipStreamSynchronize(st));
+      return ((volatile int*)n->updateRequiredHost)[1] > n->buildDrift ? 1 : 0;
    }
+   HIP_CHECK(hipStreamSynchronize(st));
+   *n->updateRequiredHost = 0;                               // (raised only; cleared here, when nothing that writes it is in flight)
+   hipLaunchKernelGGL(NeighborListUpdateRequired, dim3(ceilDiv((long)sim->boxes.nLocalBoxes * sim->maxAtoms, 256)), dim3(256), 0, st,
+                      sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, n->lastR.x, n->lastR.y, n->lastR.z,
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, n->skinDistanceHalf2, n->updateRequired);
+   LAUNCH_CHECK();
+   HIP_CHECK(hipStreamSynchronize(st));
    const int v = *(volatile int*)n->updateRequiredHost;
    *n->updateRequiredHost = 0;
    return v;
 }
 
-extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
+extern "C" int comdNeighborListUpdateDeferredGpu(SimGpu* sim)
+{
+   NeighborListGpu* n = &sim->atoms.neighborList;
+   const char* envSync = getenv("COMD_NL_SYNC");
+   const bool forceSync = envSync && atoi(envSync) != 0;
+   if (forceSync || !n->checkFused || n->forceRebuildFlag || n->lastInterval <= 0 || n->softHalf2 <= R(0.0)) return neighborListUpdateRequiredGpu(sim);
+   n->checkFused = 0;
+   const int G = n->driftCount, k = G - n->buildDrift;       // drift kernels so far, since the build
+   const volatile int* f = (volatile int*)n->updateRequiredHost;
+   // what drifts up to G - 2 found must be known: drift kernel G - 1 says so as it starts (f[3] = G - 2).  It has started long ago unless the host ran ahead of the
+   // device by more than a step; then wait -- on the pinned word, not on the stream
+   if (k >= 3) {
+      long spins = 0;
+      while (f[3] < G - 2) { __builtin_ia32_pause(); if (++spins > 200000000L) { HIP_CHECK(hipStreamSynchronize(S(sim->boundary_stream))); break; } }
+   }
+   const int hard = f[1], soft = f[2];
+   if (hard > n->buildDrift && hard < G) {                   // the force evaluation behind drift `hard` used these lists beyond skin/2
+      fprintf(stderr, "Rank %d: an atom moved more than skin/2 between two displacement tests of the deferred list check (margin %.1f %% of skin/2 after lists that lasted %d steps): "
+                      "the neighbour lists were used beyond their validity.  COMD_NL_SYNC=1 tests every step before the force (blocking).\n",
+              g_rank, 100.0 * (1.0 - sqrt((double)n->softHalf2 / (double)n->skinDistanceHalf2)), n->lastInterval);
+      exit(-1);
+   }
+   return soft > n->buildDrift ? 1 : 0;
+}
+
+static void buildNeighborListImpl(SimGpu* sim, int method, int boundaryFlag)
 {
    (void)method; (void)boundaryFlag;
    NeighborListGpu* n = &sim->atoms.neighborList;
@@ -1584,11 +1626,26 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
    if (n->slabFormat == 4) {
       // rows of the brick kernel: the cells were just re-binned, so the image is sized again for the fullest block; STEP 0 sweeps every brick once
       hipStream_t st = S(sim->boundary_stream);
-      eamBrickBuildLists(sim, st, sim->eam_pot.phiS.coefficients != nullptr);      // (sizes the image as well)
+      // The brick lists (and the image size they were made for) are kept from build to build: making them costs the host a read-back of the occupancies and 1 ms in
+      // which the device idles.  What tells when they are stale is the build kernel itself -- it counts the bricks whose block no longer fits the image (they take the
+      // thread-per-atom form, correct and slow) -- read back asynchronously and looked at by the NEXT build, which then makes the lists again.
+      if (!n->brickStatsMirror) { HIP_CHECK(hipHostMalloc((void**)&n->brickStatsMirror, 64, hipHostMallocDefault)); memset(n->brickStatsMirror, 0, 64); }
+      if (n->brickStatsEvent) {
+         HIP_CHECK(hipEventSynchronize((hipEvent_t)n->brickStatsEvent));      // recorded a whole list life ago
+         if (n->brickStatsMirror[1] > 0) sim->eam_pot.brickListsValid = 0;
+      }
+      if (getenv("COMD_EAM_LISTS_EVERY_BUILD")) sim->eam_pot.brickListsValid = 0;      // (A/B runs, tests)
+      if (!sim->eam_pot.brickListsValid) {
+         eamBrickBuildLists(sim, st, sim->eam_pot.phiS.coefficients != nullptr);      // (sizes the image as well)
+         sim->eam_pot.brickListsValid = 1;
+      }
       EamArgs a = makeEamArgs(sim, sim->boxes.nLocalBoxes, nullptr);
       if (!sim->eam_pot.brickStats) sim->eam_pot.brickStats = dalloc<int>(2);
       HIP_CHECK(hipMemsetAsync(sim->eam_pot.brickStats, 0, 2 * sizeof(int), st));
       launchEamBrick<0>(sim, a, sim->boxes.nLocalBoxes, nullptr, st, 0, true, THREAD_ATOM_NL);
+      HIP_CHECK(hipMemcpyAsync(n->brickStatsMirror, sim->eam_pot.brickStats, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      if (!n->brickStatsEvent) { hipEvent_t e; HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming)); n->brickStatsEvent = (void*)e; }
+      HIP_CHECK(hipEventRecord((hipEvent_t)n->brickStatsEvent, st));
       const size_t bytes = (size_t)sim->boxes.nLocalBoxes * sim->maxAtoms * sizeof(real_t);
       HIP_CHECK(hipMemcpyAsync(n->lastR.x, sim->atoms.r.x, bytes, hipMemcpyDeviceToDevice, st));
       HIP_CHECK(hipMemcpyAsync(n->lastR.y, sim->atoms.r.y, bytes, hipMemcpyDeviceToDevice, st));
@@ -1657,6 +1714,21 @@ extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
    LAUNCH_CHECK();
    n->forceRebuildFlag = 0;
    n->nBuilds++;
+}
+
+extern "C" void buildNeighborListGpu(SimGpu* sim, int method, int boundaryFlag)
+{
+   NeighborListGpu* n = &sim->atoms.neighborList;
+   const int had = n->nBuilds;
+   buildNeighborListImpl(sim, method, boundaryFlag);
+   // bookkeeping of the deferred displacement test (comdNeighborListUpdateDeferredGpu): how long the previous lists lasted sizes the margin of these
+   n->lastInterval = had > 0 ? n->driftCount - n->buildDrift : 0;
+   n->buildDrift = n->driftCount;
+   double frac = n->lastInterval > 0 ? 4.0 / n->lastInterval : 0.0;      // two steps' worth of twice the average growth per step
+   if (frac < 0.1) frac = 0.1;
+   if (frac > 0.6) frac = 0.6;
+   { const char* e = getenv("COMD_NL_MARGIN"); if (e && atof(e) >= 0.0 && atof(e) < 1.0) frac = atof(e); }      // tests: force the stop
+   n->softHalf2 = n->lastInterval > 0 ? (real_t)((1.0 - frac) * (1.0 - frac)) * n->skinDistanceHalf2 : R(0.0);
 }
 
 extern "C" int pairlistUpdateRequiredGpu(SimGpu* sim) { return neighborListUpdateRequiredGpu(sim); }

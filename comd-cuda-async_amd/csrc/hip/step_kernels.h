@@ -39,12 +39,25 @@ void AdvancePosition(real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* _
 
 // [round 4] Verlet lists: the drift kernels also answer "has an atom moved more than skin/2 since the list build?" (gpu_kernels.cu:1087-1110) for the
 // positions they have just written -- the separate pass over r and lastR (40 us at EAM 80^3) is gone.  lastX == NULL: no lists, nothing is checked.
-struct SkinCheck { const real_t* lastX; const real_t* lastY; const real_t* lastZ; real_t skinHalf2; int* flag; };
+struct SkinCheck { const real_t* lastX; const real_t* lastY; const real_t* lastZ; real_t skinHalf2, softHalf2; int* hard; int* soft; int* progress; int stamp;
+                   const int* status; int* statusMirror; };      // (and, always: the device status words mirrored into pinned memory by the first thread -- comdPollStatus reads them there)
+// The flags are not booleans: a drift kernel that finds an atom beyond a threshold writes ITS OWN number (drift kernels of a simulation are numbered from 1 and never
+// overlap on their stream), so a flag holds the number of the last drift that saw a violation and never has to be cleared -- the host compares it with the number the
+// last list build was made at.  hard: (skin / 2)^2, the reference's rule; soft: a little less, for the host that decides two drifts late (comd_device.hip).
+// progress: drift kernel G says "drift G - 1 and everything before it is done" as it starts (kernels of a stream do not overlap): how the host knows how far behind
+// the device is without an event or a synchronisation (an hipEventRecord behind every drift kernel cost 0.1 ms per step at EAM 80^3).
+__device__ __forceinline__ void skinProgress(const SkinCheck& sk)
+{
+   if (blockIdx.x != 0 || threadIdx.x != 0) return;
+   if (sk.lastX) *sk.progress = sk.stamp - 1;
+   if (sk.statusMirror) { sk.statusMirror[0] = sk.status[0]; sk.statusMirror[1] = sk.status[1]; sk.statusMirror[2] = sk.status[2]; sk.statusMirror[3] = sk.status[3]; }
+}
 __device__ __forceinline__ void skinCheck(const SkinCheck& sk, long s, real_t x, real_t y, real_t z)
 {
    if (!sk.lastX) return;
    const real_t dx = x - sk.lastX[s], dy = y - sk.lastY[s], dz = z - sk.lastZ[s];
-   if (dx*dx + dy*dy + dz*dz > sk.skinHalf2) *sk.flag = 1;
+   const real_t d2 = dx*dx + dy*dy + dz*dz;
+   if (d2 > sk.softHalf2) { *sk.soft = sk.stamp; if (d2 > sk.skinHalf2) *sk.hard = sk.stamp; }
 }
 
 // half kick followed by the drift in one pass (same operations, same order, as AdvanceVelocity then AdvancePosition)
@@ -55,6 +68,7 @@ void AdvanceVelocityPosition(real_t* __restrict__ rx, real_t* __restrict__ ry, r
                              const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
                              const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick, real_t dtDrift, SkinCheck sk)
 {
+   skinProgress(sk);
    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(tid / cap);
    if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
@@ -75,6 +89,7 @@ void AdvanceVelocityVelocityPosition(real_t* __restrict__ rx, real_t* __restrict
                                      const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
                                      const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick1, real_t dtKick2, real_t dtDrift, SkinCheck sk)
 {
+   skinProgress(sk);
    const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
    const int c = (int)(tid / cap);
    if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;

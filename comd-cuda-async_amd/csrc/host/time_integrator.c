@@ -4,6 +4,7 @@
  * include/comd_hip.h; the only blocking device round-trip per step on one rank is none at all
  * (the reference has >= 20) -- energies are fetched every printRate steps. */
 #include "comd_host.h"
+#include <stdlib.h>
 
 static void advanceVelocity(SimFlat* s, real_t dt) { advanceVelocityGpu(&s->gpu, dt); }
 
@@ -105,7 +106,13 @@ static void redistributeAtomsCells(SimFlat* sim, int overlapInterior);
 static void redistributeAtomsNL(SimFlat* sim)
 {
    SimGpu* g = &sim->gpu;
-   int need = neighborListUpdateRequiredGpu(g), needAll = 0;
+   /* The reference's rule (gpu_kernels.cu:1449-1484): has an atom moved more than skin/2 since the build?  Asked of the drift kernel that has just run -- a stream
+    * synchronisation per step (35 us of device idle at EAM 80^3).  COMD_NL_DEFERRED=1: the form that never drains the stream (comd_hip.h
+    * comdNeighborListUpdateDeferredGpu: decided two drifts late against a threshold lowered by what two steps can add) -- measured at -1 % of the step, because the
+    * lower threshold rebuilds the lists every 18 instead of every 22 steps; the blocking form stays the default. */
+   static int deferred = -1;
+   if (deferred < 0) { const char* e = getenv("COMD_NL_DEFERRED"); deferred = e && atoi(e) != 0; }
+   int need = deferred ? comdNeighborListUpdateDeferredGpu(g) : neighborListUpdateRequiredGpu(g), needAll = 0;
    startTimer(commReduceTimer);
    maxIntParallel(&need, &needAll, 1);
    stopTimer(commReduceTimer);

@@ -96,6 +96,7 @@ typedef struct EamPotentialGpuSt {
    int     brickGroupBy, brickGroupBz; /* the brick shape the groups were built for */
    int*    brickList;                  /* device [2][brickListStride]: the bricks of group 1, of group 2 (what a group launch's workgroups take) */
    int     brickCount[2], brickListStride;
+   int     brickListsValid;            /* host: the lists below were made for occupancies that still fit (remade when a build finds a brick that does not) */
    int     brickCountAll;              /* Verlet rows (slabFormat 4): the lists are made by every list build -- [0] boundary bricks, [1] the others, [2 * stride ..) all; an entry is a
                                         * brick number, or with bits 28-29 set the lower (1) / upper (2) z half of a brick whose block would outgrow the LDS image */
    int*    cellSel;                    /* device [nLocalBoxes] */
@@ -126,8 +127,13 @@ typedef struct NeighborListGpuSt {
    int    maxNeighbors;                /* rows per cell (gpu_neighborList.c:50 MAXNEIGHBORLISTSIZE) */
    vec_t  lastR;                       /* device [nLocalBoxes * maxAtoms]: positions at the last build */
    int*   updateRequired;              /* device view of updateRequiredHost */
-   int*   updateRequiredHost;          /* pinned host [1]: raised by the displacement test (the fused drift kernels or NeighborListUpdateRequired), cleared by the host */
-   int    checkFused;                  /* host: a fused drift kernel has tested the positions it wrote since the last neighborListUpdateRequiredGpu */
+   int*   updateRequiredHost;          /* pinned host [16]: [0] raised by NeighborListUpdateRequired (the stand-alone test), cleared by the host; [1] / [2] the number of the last
+                                        * fused drift kernel that saw an atom beyond skin/2 / beyond the soft threshold since -- never cleared, compared with buildDrift;
+                                        * [3] progress: drift kernel G writes G - 1 as it starts */
+   int    checkFused;                  /* host: a fused drift kernel has tested the positions it wrote since the last decision */
+   int    driftCount, buildDrift;      /* host: fused drift kernels launched so far; the count when the lists were last built */
+   int    lastInterval;                /* host: drifts the previous lists lasted (0: unknown) -- sizes the margin of the deferred decision */
+   real_t softHalf2;                   /* host: (skin/2 - margin)^2 of the current lists */
    real_t skinDistance, skinDistance2, skinDistanceHalf2;
    /* LJ (cells of <= 512 slots): the list is kept per group of stencil cells (the 3 x-planes of 9 cells) as 16-bit indices into the
     * LDS staging of that group: list16[((c*3 + g)*slabRows + k)*maxAtoms + i], nNeighbors[(c*3 + g)*maxAtoms + i]; `list` is unused */
@@ -146,6 +152,8 @@ typedef struct NeighborListGpuSt {
    unsigned* brickRows;                /* slabFormat 4: device [nLocalBoxes][brickRounds][brickQuads][64] uint4 */
    unsigned short* brickRowCount;      /* slabFormat 4: device [nLocalBoxes * maxAtoms] list lengths */
    int    brickRowLen, brickRounds, brickQuads, brickRoundAtoms;
+   int*   brickStatsMirror;            /* pinned host [2]: {longest row, bricks that did not fit the image} of the last build, copied behind it; the next build looks */
+   void*  brickStatsEvent;             /* recorded behind that copy */
    int    forceRebuildFlag;            /* host: the next neighborListUpdateRequiredGpu answers 1 without looking */
    int    nBuilds;                     /* host: builds since AllocateGpu */
 } NeighborListGpu;
@@ -201,6 +209,8 @@ typedef struct SimGpuSt {
                                         * once -- same e[], dfEmbed[] after the pair of calls, one launch fewer */
    /* scan scratch of the reference-side adapter (include/comd_hip_shim.h comdShimOffsets): the reference's per-face partial_sums arrays hold nCells ints,
     * the scans here need nCells + 1; grown on demand, freed by DestroyGpu; the library itself never touches it */
+   int*         statusMirrorDev;       /* device view of the four status words' mirror in `pinned`: the fused drift kernels refresh it as they start */
+   int          statusMirrored;        /* host: a fused drift kernel has been launched since the last comdPollStatus */
    void*        statusEvent;           /* comdPollStatus: recorded behind the last status mirror (pinned[32..35]), NULL before the first poll */
    int*         adapterScan;
    int          adapterScanCap;
@@ -453,6 +463,13 @@ void emptyNeighborListGpu(SimGpu* sim, int boundaryFlag);
 /* neighborListUpdateRequiredGpu(SimGpu*), gpu_kernels.cu:1449-1484: 1 when forceRebuildFlag is set or some local atom has moved
  * more than skin/2 since the build (blocking read of one flag).  THIS rank's answer; the caller reduces over ranks. */
 int  neighborListUpdateRequiredGpu(SimGpu* sim);
+/* The same question WITHOUT draining the stream: answered from what the drift kernels up to the one TWO before the last found (every drift kernel reports, as it starts,
+ * that its predecessor is done -- a word in pinned memory the host waits on if it ever runs more than a step ahead; no event, no synchronisation: the host stays ahead of
+ * the device and kernel launches keep hiding behind the force kernels -- the blocking form costs 0.1 ms per step at EAM 80^3).  To be safe two drifts late the test uses a
+ * threshold below skin/2 by the displacement two steps can add, estimated as twice the average growth over the previous lists' life (4 / lastInterval of skin/2, at least
+ * 10 %, at most 60 %); the exact rule is still evaluated by every drift kernel, and lists that turn out to have been used beyond skin/2 stop the run with a message
+ * (COMD_NL_SYNC=1 selects the blocking form).  First lists of a run, or positions changed by anything but the fused drift kernels: the blocking form. */
+int  comdNeighborListUpdateDeferredGpu(SimGpu* sim);
 /* neighborListForceRebuildGpu(NeighborListGpu*), gpu_neighborList.c:88-93: the reference's signature (a host function there; an object of the
  * reference that defines it too simply takes precedence over the library's) */
 void neighborListForceRebuildGpu(NeighborListGpu* neighborList);

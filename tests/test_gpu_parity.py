@@ -325,6 +325,41 @@ def test_neighbor_list_trace_matches_reference(gpu, key, skin):
         assert sim.energy()[2] == 4 * ref["nx"] ** 3
 
 
+@pytest.mark.parametrize("eam,skin", [(1, 0.02), (1, 0.1), (0, 0.02)])
+def test_deferred_list_check_is_the_blocking_check_made_two_drifts_early(eam, skin):
+    """COMD_NL_DEFERRED=1: the host asks "must the lists be rebuilt?" without draining the stream -- answered from what the drift kernels up to the one two before the last
+    found, against a threshold below skin/2 by what two steps can add (comd_hip.h comdNeighborListUpdateDeferredGpu).  Against the blocking form of the reference (the
+    default: the exact rule tested after every drift): the same physics -- energies per atom agree to the trace tolerance, no atom lost -- and rebuilds that come a little
+    earlier, never later: at least as many builds, not many more.  (A child process per mode: the host reads the switch once.)"""
+    import subprocess
+    import sys
+    key = "eam_20" if eam else "lj_20"
+    ref = S[key]
+    code = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+import __graft_entry__ as ge
+pkg = ge.load_package()
+pkg.setup_gpu(0, 0, verbose=False); pkg.init_parallel(0, 1, None)
+with pkg.Simulation(%r) as sim:
+    sim.step(100)
+    ep, ek, n = sim.energy()
+    sim.sum_atoms()
+    print(json.dumps({"e": (ep + ek) / n, "builds": sim.nl_builds, "atoms": sim.energy()[2]}))
+''' % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), _args(ref["nx"], ref["eam"], 0.0, "thread_atom_nl", ["-S", skin]))
+    out = {}
+    for mode in ("0", "1"):
+        proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, COMD_NL_DEFERRED=mode))
+        assert proc.returncode == 0, proc.stderr[-1500:]
+        out[mode] = json.loads(proc.stdout.strip().splitlines()[-1])
+        assert out[mode]["atoms"] == 4 * ref["nx"] ** 3
+        assert abs(out[mode]["e"] - ref["E_at"]["100"]) < TOL["energy_per_atom_trace"], (mode, out[mode])
+    b_sync, b_def = out["0"]["builds"], out["1"]["builds"]
+    assert b_sync <= b_def <= int(1.7 * b_sync) + 2, (b_sync, b_def)
+    if skin < 0.05 and eam:
+        assert b_sync > 5
+
+
 @pytest.mark.parametrize("eam,n,extra", [(0, 12, ()), (1, 8, ()), (1, 8, ("-t", "setfl", "-p", "Cu01.eam.alloy"))])
 def test_neighbor_list_global_slot_format(gpu, orc, monkeypatch, eam, n, extra):
     """The plain list format (32-bit global slots, neighbours gathered from global memory) is what cells too large for the LDS
