@@ -299,7 +299,7 @@ class Simulation:
         a, b = (ctypes.c_int * 4)(), (ctypes.c_int * 3)()
         hip.comdForcePathInfo(gpu, a)
         hip.comdEamBrickStats(gpu, b)
-        return {"lj_candidate_lists_active": bool(a[0]), "eam_brick_image_records": a[1], "neighbor_list_format": a[2], "eam_brick_cells": a[3],
+        return {"lj_candidate_lists_active": bool(a[0]), "eam_brick_image_records": a[1], "neighbor_list_format": a[2], "eam_brick_cells": a[3] & 255, "eam_brick_lists_made": a[3] >> 8,
                 "eam_bricks_in_thread_per_atom_fallback": b[0], "eam_bricks_per_launch": b[1]}
 
     # --- results ---

@@ -952,7 +952,7 @@ static void eamBrickBuildLists(SimGpu* sim, hipStream_t st, int spline)
    if (cap > 4096) cap = 4096;
    { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) cap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force halves and the fall-back
    sim->eam_pot.brickImageCap = cap;
-   const int headroom = cap / 64 > 8 ? cap / 64 : 8;
+   const int headroom = cap / 32 > 8 ? cap / 32 : 8;
    // the lists: [0, stride) bricks that hold a boundary cell, [stride, 2 stride) the others, [2 stride, 3 stride) all of them; brick order, halves adjacent
    std::vector<char> isBoundary((size_t)sim->boxes.nLocalBoxes, 0);
    for (int c : boundary) if (c >= 0 && c < sim->boxes.nLocalBoxes) isBoundary[c] = 1;
@@ -967,7 +967,7 @@ static void eamBrickBuildLists(SimGpu* sim, hipStream_t st, int spline)
       for (int dz = 0; dz < b.bz; ++dz) for (int dy = 0; dy < b.by; ++dy)
          if (by0 + dy < gy && bz0 + dz < gz) group[comdBoxFromTuple(&hg, x, by0 + dy, bz0 + dz)] = any ? 1 : 2;
       const int g = any ? 0 : 1;
-      // (a brick within 1.5 % of the image goes in halves too: the lists outlive this build -- atoms wander between cells from one build to the next -- and a brick
+      // (a brick within 3 % of the image goes in halves too: the lists outlive this build -- atoms wander between cells from one build to the next -- and a brick
       // that outgrows the image later takes the thread-per-atom form until the lists are made again)
       const bool halves = whole[i] + 1 > cap - headroom && b.bz % 2 == 0 && bz0 + b.bz / 2 < gz;      // (an upper half outside the grid would be an empty workgroup)
       const int e[2] = { halves ? i | (1 << 28) : i, i | (2 << 28) };
@@ -981,6 +981,7 @@ static void eamBrickBuildLists(SimGpu* sim, hipStream_t st, int spline)
    HIP_CHECK(hipStreamSynchronize(st));                      // (the vectors go out of scope; the other stream of the overlap mode reads the lists too)
    sim->eam_pot.brickCount[0] = cnt[0]; sim->eam_pot.brickCount[1] = cnt[1]; sim->eam_pot.brickCountAll = cnt[2]; sim->eam_pot.brickListStride = stride;
    sim->eam_pot.brickGroupBy = b.by; sim->eam_pot.brickGroupBz = b.bz;
+   sim->eam_pot.brickListMakes++;
 }
 
 template <int STEP>
@@ -1106,7 +1107,7 @@ extern "C" void comdForcePathInfo(SimGpu* sim, int out[4])
    out[0] = sim->lj_pot.packedCap > 0 ? 1 : 0;
    out[1] = sim->eam_pot.brickImageCap;
    out[2] = sim->atoms.neighborList.slabFormat;
-   out[3] = sim->eam_pot.brickBy * sim->eam_pot.brickBz;
+   out[3] = sim->eam_pot.brickBy * sim->eam_pot.brickBz + 256 * sim->eam_pot.brickListMakes;      // (cells per brick in the low byte, times the brick lists were made above)
 }
 
 extern "C" void comdEamBrickStats(SimGpu* sim, int out[3])

@@ -96,6 +96,7 @@ typedef struct EamPotentialGpuSt {
    int     brickGroupBy, brickGroupBz; /* the brick shape the groups were built for */
    int*    brickList;                  /* device [2][brickListStride]: the bricks of group 1, of group 2 (what a group launch's workgroups take) */
    int     brickCount[2], brickListStride;
+   int     brickListMakes;             /* host: times the brick lists were made (eamBrickBuildLists) */
    int     brickListsValid;            /* host: the lists below were made for occupancies that still fit (remade when a build finds a brick that does not) */
    int     brickCountAll;              /* Verlet rows (slabFormat 4): the lists are made by every list build -- [0] boundary bricks, [1] the others, [2 * stride ..) all; an entry is a
                                         * brick number, or with bits 28-29 set the lower (1) / upper (2) z half of a brick whose block would outgrow the LDS image */
@@ -333,7 +334,7 @@ void comdEamBrickStats(SimGpu* sim, int out[3]);
 /* cta_cell: have the next launch read the occupancies again and size the image for the fullest block (call between force evaluations) */
 void comdEamBrickResize(SimGpu* sim);
 /* what the force wrappers decided for this simulation: {LJ thread_atom candidate lists in use (0: the plain 27-cell walk -- lists did not fit the device memory),
- * records of the EAM brick image, Verlet-list format (NeighborListGpu.slabFormat), cells per EAM brick} */
+ * records of the EAM brick image, Verlet-list format (NeighborListGpu.slabFormat), cells per EAM brick + 256 x the times the brick lists of the list method were made} */
 void comdForcePathInfo(SimGpu* sim, int out[4]);
 /* updateNeighborsGpu[Async], gpu_kernels.cu:251-279: the reference materialises 27*MAXATOMS neighbour
  * offsets per cell for its cta_cell/warp_atom EAM kernels; ours gather from the cell table directly,
