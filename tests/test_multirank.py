@@ -141,6 +141,28 @@ def test_bench_self_check_catches_a_run_that_differs(tmp_path):
     assert line["sized_matches_handshake"] is False
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("pot,ranks", [("lj", 2), ("eam", 4)])
+def test_bench_through_the_launcher_with_several_ranks(pot, ranks):
+    """The driver's command line for N > 1 -- python -m torch.distributed.run --nproc-per-node N bench.py --gpus N -- rehearsed on ONE device: the ranks share the GPU
+    (COMD_FORCE_DEVICE=0), RCCL refuses a communicator with one device twice, and --allow-host-staged sends the halo messages over gloo instead (the line says
+    "measured": false).  Everything else is the N > 1 path of the day the ranks have a GPU each: decomposition 2x1x1 / 2x2x1 (one / two message axes, the rest mirrored),
+    overlap mode, the sized halo protocol checked against the handshake run, one JSON line from rank 0, exit code 0 on every rank."""
+    import json
+    env = dict(os.environ, COMD_FORCE_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", str(ranks), "--pot", pot, "--nx", "16", "--steps", "4", "--warmup", "2", "--allow-host-staged"]
+    proc = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [l for l in proc.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == ranks and line["config"]["decomposition"] == {2: "2x1x1", 4: "2x2x1"}[ranks] and line["config"]["halo_overlap"] is True
+    assert line["measured"] is False and "gloo-host-staged" in line["config"]["transport"]
+    assert line["sized_matches_handshake"] is True and line["handshake_run"]["d_atoms"] == 0
+    assert abs(line["eFinal_over_eInitial"] - 1.0) < 1e-4
+
+
 def test_bench_refuses_to_run_many_ranks_without_rccl():
     """Two ranks on a machine without a GPU (no device, hence no RCCL communicator): bench.py must exit non-zero on every rank instead of
     printing a host-staged number -- a SCALE record produced that way would look measured.  Runs here, on the CPU."""
