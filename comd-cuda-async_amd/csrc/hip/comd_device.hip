@@ -1255,21 +1255,30 @@ extern "C" void updateNeighborsGpu(SimGpu*, int*) {}
 extern "C" void updateNeighborsGpuAsync(SimGpu*, int*, int, int*, comdStream_t) {}
 
 // ---- integrator + energy -----------------------------------------------------------------------------------------
+// lanes of a 256-thread workgroup that serve one cell in the integrator kernels (step_kernels.h COMD_CELL_SLOTS): the power of two that covers the usual occupancy of a
+// cell of this capacity -- capacities are the lattice maximum + 10 % + 8, and cells hold about a third of that (EAM) or 60 % (LJ, multiples of 64)
+static int integratorLaneBits(const SimGpu* sim)
+{
+   const int cap = sim->maxAtoms;
+   return cap <= 48 ? 4 : cap <= 96 ? 5 : cap <= 192 ? 6 : 8;
+}
+static dim3 integratorGrid(const SimGpu* sim) { return dim3((unsigned)ceilDiv(sim->boxes.nLocalBoxes, 256 >> integratorLaneBits(sim))); }
+
 extern "C" void advanceVelocityGpu(SimGpu* sim, real_t dt)
 {
    const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
-   hipLaunchKernelGGL(AdvanceVelocity, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
+   hipLaunchKernelGGL(AdvanceVelocity, integratorGrid(sim), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z, sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z,
-                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dt);
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dt, integratorLaneBits(sim));
    LAUNCH_CHECK();
 }
 
 extern "C" void advancePositionGpu(SimGpu* sim, real_t dt)
 {
    const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
-   hipLaunchKernelGGL(AdvancePosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
+   hipLaunchKernelGGL(AdvancePosition, integratorGrid(sim), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
-                      sim->atoms.iSpecies, sim->species_mass, sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dt);
+                      sim->atoms.iSpecies, sim->species_mass, sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dt, integratorLaneBits(sim));
    LAUNCH_CHECK();
 }
 
@@ -1291,10 +1300,10 @@ extern "C" void advanceVelocityPositionGpu(SimGpu* sim, real_t dtKick, real_t dt
 {
    const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
    const SkinCheck sk = skinCheckOf(sim);
-   hipLaunchKernelGGL(AdvanceVelocityPosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
+   hipLaunchKernelGGL(AdvanceVelocityPosition, integratorGrid(sim), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
                       sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.iSpecies, sim->species_mass,
-                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick, dtDrift, sk);
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick, dtDrift, sk, integratorLaneBits(sim));
    LAUNCH_CHECK();
 }
 
@@ -1302,10 +1311,10 @@ extern "C" void advanceVelocityVelocityPositionGpu(SimGpu* sim, real_t dtKick1, 
 {
    const long slots = (long)sim->boxes.nLocalBoxes * sim->maxAtoms;
    const SkinCheck sk = skinCheckOf(sim);
-   hipLaunchKernelGGL(AdvanceVelocityVelocityPosition, dim3(ceilDiv(slots, 256)), dim3(256), 0, S(sim->boundary_stream),
+   hipLaunchKernelGGL(AdvanceVelocityVelocityPosition, integratorGrid(sim), dim3(256), 0, S(sim->boundary_stream),
                       sim->atoms.r.x, sim->atoms.r.y, sim->atoms.r.z, sim->atoms.p.x, sim->atoms.p.y, sim->atoms.p.z,
                       sim->atoms.f.x, sim->atoms.f.y, sim->atoms.f.z, sim->atoms.iSpecies, sim->species_mass,
-                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick1, dtKick2, dtDrift, sk);
+                      sim->boxes.nAtoms, sim->boxes.nLocalBoxes, sim->maxAtoms, dtKick1, dtKick2, dtDrift, sk, integratorLaneBits(sim));
    LAUNCH_CHECK();
 }
 

@@ -13,28 +13,31 @@
 #include "device_common.h"
 
 // ---- integrator -------------------------------------------------------------------------------------
+// [round 4] 2^laneBits threads of a 256-thread workgroup serve one cell and loop over its atoms (slot = lane, lane + 2^laneBits, ...).  Round 3 ran a thread per
+// SLOT: at 14 atoms in 44 slots (EAM with lists) or 10 in 24 two threads in three found nothing to do.  The host picks the lanes from the capacity
+// (comd_device.hip integratorLaneBits): a cell fuller than its lanes takes a second trip, no atom is ever skipped.
+#define COMD_CELL_SLOTS(laneBits) \
+   const int c = (int)blockIdx.x * (256 >> (laneBits)) + ((int)threadIdx.x >> (laneBits)); \
+   if (c >= nLocalBoxes) return; \
+   for (long tid = (long)c * cap + ((int)threadIdx.x & ((1 << (laneBits)) - 1)), tidEnd = (long)c * cap + nAtoms[c]; tid < tidEnd; tid += (1 << (laneBits)))
 __global__ __launch_bounds__(256)
 void AdvanceVelocity(real_t* __restrict__ px, real_t* __restrict__ py, real_t* __restrict__ pz,
                      const real_t* __restrict__ fx, const real_t* __restrict__ fy, const real_t* __restrict__ fz,
-                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dt)
+                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dt, int laneBits)
 {
-   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-   const int c = (int)(tid / cap);
-   if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
-   px[tid] += dt * fx[tid]; py[tid] += dt * fy[tid]; pz[tid] += dt * fz[tid];
+   COMD_CELL_SLOTS(laneBits) { px[tid] += dt * fx[tid]; py[tid] += dt * fy[tid]; pz[tid] += dt * fz[tid]; }
 }
 
 __global__ __launch_bounds__(256)
 void AdvancePosition(real_t* __restrict__ rx, real_t* __restrict__ ry, real_t* __restrict__ rz,
                      const real_t* __restrict__ px, const real_t* __restrict__ py, const real_t* __restrict__ pz,
                      const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
-                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dt)
+                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dt, int laneBits)
 {
-   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-   const int c = (int)(tid / cap);
-   if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
-   const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];  // same expression order as timestep.c:168-173
-   rx[tid] += dt * px[tid] * invMass; ry[tid] += dt * py[tid] * invMass; rz[tid] += dt * pz[tid] * invMass;
+   COMD_CELL_SLOTS(laneBits) {
+      const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];  // same expression order as timestep.c:168-173
+      rx[tid] += dt * px[tid] * invMass; ry[tid] += dt * py[tid] * invMass; rz[tid] += dt * pz[tid] * invMass;
+   }
 }
 
 // [round 4] Verlet lists: the drift kernels also answer "has an atom moved more than skin/2 since the list build?" (gpu_kernels.cu:1087-1110) for the
@@ -66,18 +69,17 @@ void AdvanceVelocityPosition(real_t* __restrict__ rx, real_t* __restrict__ ry, r
                              real_t* __restrict__ px, real_t* __restrict__ py, real_t* __restrict__ pz,
                              const real_t* __restrict__ fx, const real_t* __restrict__ fy, const real_t* __restrict__ fz,
                              const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
-                             const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick, real_t dtDrift, SkinCheck sk)
+                             const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick, real_t dtDrift, SkinCheck sk, int laneBits)
 {
    skinProgress(sk);
-   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-   const int c = (int)(tid / cap);
-   if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
-   const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];
-   const real_t x = px[tid] + dtKick * fx[tid], y = py[tid] + dtKick * fy[tid], z = pz[tid] + dtKick * fz[tid];
-   px[tid] = x; py[tid] = y; pz[tid] = z;
-   const real_t nx = rx[tid] + dtDrift * x * invMass, ny = ry[tid] + dtDrift * y * invMass, nz = rz[tid] + dtDrift * z * invMass;
-   rx[tid] = nx; ry[tid] = ny; rz[tid] = nz;
-   skinCheck(sk, tid, nx, ny, nz);
+   COMD_CELL_SLOTS(laneBits) {
+      const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];
+      const real_t x = px[tid] + dtKick * fx[tid], y = py[tid] + dtKick * fy[tid], z = pz[tid] + dtKick * fz[tid];
+      px[tid] = x; py[tid] = y; pz[tid] = z;
+      const real_t nx = rx[tid] + dtDrift * x * invMass, ny = ry[tid] + dtDrift * y * invMass, nz = rz[tid] + dtDrift * z * invMass;
+      rx[tid] = nx; ry[tid] = ny; rz[tid] = nz;
+      skinCheck(sk, tid, nx, ny, nz);
+   }
 }
 
 // second half kick of one step + first half kick and drift of the next, one pass (same operations, same order, as AdvanceVelocity followed
@@ -87,20 +89,19 @@ void AdvanceVelocityVelocityPosition(real_t* __restrict__ rx, real_t* __restrict
                                      real_t* __restrict__ px, real_t* __restrict__ py, real_t* __restrict__ pz,
                                      const real_t* __restrict__ fx, const real_t* __restrict__ fy, const real_t* __restrict__ fz,
                                      const int* __restrict__ iSpecies, const real_t* __restrict__ speciesMass,
-                                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick1, real_t dtKick2, real_t dtDrift, SkinCheck sk)
+                                     const int* __restrict__ nAtoms, int nLocalBoxes, int cap, real_t dtKick1, real_t dtKick2, real_t dtDrift, SkinCheck sk, int laneBits)
 {
    skinProgress(sk);
-   const long tid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-   const int c = (int)(tid / cap);
-   if (c >= nLocalBoxes || (int)(tid - (long)c * cap) >= nAtoms[c]) return;
-   const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];
-   const real_t gx = fx[tid], gy = fy[tid], gz = fz[tid];
-   real_t x = px[tid] + dtKick1 * gx, y = py[tid] + dtKick1 * gy, z = pz[tid] + dtKick1 * gz;
-   x += dtKick2 * gx; y += dtKick2 * gy; z += dtKick2 * gz;
-   px[tid] = x; py[tid] = y; pz[tid] = z;
-   const real_t nx = rx[tid] + dtDrift * x * invMass, ny = ry[tid] + dtDrift * y * invMass, nz = rz[tid] + dtDrift * z * invMass;
-   rx[tid] = nx; ry[tid] = ny; rz[tid] = nz;
-   skinCheck(sk, tid, nx, ny, nz);
+   COMD_CELL_SLOTS(laneBits) {
+      const real_t invMass = R(1.0) / speciesMass[iSpecies[tid]];
+      const real_t gx = fx[tid], gy = fy[tid], gz = fz[tid];
+      real_t x = px[tid] + dtKick1 * gx, y = py[tid] + dtKick1 * gy, z = pz[tid] + dtKick1 * gz;
+      x += dtKick2 * gx; y += dtKick2 * gy; z += dtKick2 * gz;
+      px[tid] = x; py[tid] = y; pz[tid] = z;
+      const real_t nx = rx[tid] + dtDrift * x * invMass, ny = ry[tid] + dtDrift * y * invMass, nz = rz[tid] + dtDrift * z * invMass;
+      rx[tid] = nx; ry[tid] = ny; rz[tid] = nz;
+      skinCheck(sk, tid, nx, ny, nz);
+   }
 }
 
 // ---- energy: stage 1 = per-block partial sums in a fixed order, stage 2 = one block adds the partials --------
