@@ -1372,7 +1372,9 @@ extern "C" void updateLinkCellsGpu(SimGpu* sim, comdStream_t stream)
    hipLaunchKernelGGL(UpdateLinkCells, dim3(ceilDiv((long)nLocal * sim->maxAtoms, 256)), dim3(256), 0, st,
                       atomArrays(sim), sim->boxes.nAtoms, sim->nAtomsPrev, sim->cellDirty, sim->status, sim->boxes, sim->maxAtoms);
    LAUNCH_CHECK();
-   launchCompactSort(sim, 0, nTotal, st);       // local cells that lost/gained atoms and halo cells that caught migrants
+   // local cells that lost/gained atoms and halo cells that caught migrants -- unless the host says nothing needs them compact before sortAtomsGpu (every axis of the atom
+   // exchange mirrored, which skips holes, and no interior force launch in between: SimGpu.skipSortAfterUpdate)
+   if (!sim->skipSortAfterUpdate) launchCompactSort(sim, 0, nTotal, st);
 }
 
 extern "C" void buildAtomListGpu(SimGpu*, comdStream_t) {}

@@ -504,6 +504,7 @@ void MirrorAtomCells(MirrorAtomsJob jb, AtomArrays at, const int* __restrict__ n
    const size_t o = (size_t)c * cap + slot;
    real_t x = R(0.0), y = R(0.0), z = R(0.0);
    int d = -1;
+   if (have && at.gid[o] < 0) have = false;                  // a hole a mover left (the cells need not have been compacted since UpdateLinkCells: comd_hip.h skipSortAfterUpdate)
    if (have) {
       x = at.rx[o] + jb.sx[face]; y = at.ry[o] + jb.sy[face]; z = at.rz[o] + jb.sz[face];
       const CellGeom g = makeGeom(boxes);

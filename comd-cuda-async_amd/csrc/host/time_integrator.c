@@ -145,7 +145,9 @@ void redistributeAtoms(SimFlat* sim)
 static void redistributeAtomsCells(SimFlat* sim, int overlapInterior)
 {
    SimGpu* g = &sim->gpu;
-   /* empties the halo cells, moves atoms that left their cell, compacts + gid-sorts the cells that changed */
+   /* empties the halo cells, moves atoms that left their cell, compacts + gid-sorts the cells that changed -- the last only when something reads the cells before
+    * sortAtomsGpu does it again: a pack kernel (an axis with a real peer) or the interior force launch of the overlap mode */
+   g->skipSortAfterUpdate = haloMirrorFirstAxis(sim->atomExchange) == 0 && !(sim->gpuAsync && overlapInterior);
    updateLinkCellsGpu(g, g->boundary_stream);
 
    if (sim->gpuAsync && overlapInterior) {

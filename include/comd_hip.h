@@ -210,6 +210,8 @@ typedef struct SimGpuSt {
                                         * once -- same e[], dfEmbed[] after the pair of calls, one launch fewer */
    /* scan scratch of the reference-side adapter (include/comd_hip_shim.h comdShimOffsets): the reference's per-face partial_sums arrays hold nCells ints,
     * the scans here need nCells + 1; grown on demand, freed by DestroyGpu; the library itself never touches it */
+   int          skipSortAfterUpdate;   /* host switch, default 0: updateLinkCellsGpu leaves the holes of the movers in place; sortAtomsGpu squeezes them.  Only when nothing reads the
+                                        * cells in between but mirrorAtomCellsGpu (which skips holes): every axis of the atom exchange mirrored, no overlap mode */
    int*         statusMirrorDev;       /* device view of the four status words' mirror in `pinned`: the fused drift kernels refresh it as they start */
    int          statusMirrored;        /* host: a fused drift kernel has been launched since the last comdPollStatus */
    void*        statusEvent;           /* comdPollStatus: recorded behind the last status mirror (pinned[32..35]), NULL before the first poll */
