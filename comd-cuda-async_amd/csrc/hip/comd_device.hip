@@ -1080,19 +1080,26 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: cta_cell needs %zu bytes of LDS for this box\n", lds); exit(-1); }
    const int grid = group ? sim->eam_pot.brickCount[group - 1] : listed ? sim->eam_pot.brickCountAll : b.geom.g[0] * b.nby * b.nbz;
    if (grid <= 0) return;
-#define COMD_LAUNCH_EAM_BRICK(STP, TAB, SPL, LST) do { \
-      allowDynamicLds((const void*)EAM_Force_cta_brick<STP, TAB, SPL, LST>, lds); \
-      hipLaunchKernelGGL((EAM_Force_cta_brick<STP, TAB, SPL, LST>), dim3(grid), dim3(64 * waves), lds, st, a, b); } while (0)
-   if (STEP == 0)        COMD_LAUNCH_EAM_BRICK(0, false, false, true);
+   // the table clamps of interpolate() are dead weight when every pair the kernel evaluates lies inside the tables: 0 < r <= cutoff (rows hold pairs inside the cutoff;
+   // listed pairs are evaluated at min(r, cutoff)), tables from x0 <= 0 up to xn >= cutoff.  COMD_EAM_CLAMP=1 keeps them (A/B runs).
+   const double rcut = sim->eam_pot.cutoff * (1.0 + 4e-16);
+   const bool clampFree = !spline && a.phi.x0 <= R(0.0) && a.rho.x0 <= R(0.0) && rcut <= (double)a.phi.xn && rcut <= (double)a.rho.xn
+                          && !(getenv("COMD_EAM_CLAMP") && atoi(getenv("COMD_EAM_CLAMP")) != 0);
+#define COMD_LAUNCH_EAM_BRICK(STP, TAB, SPL, LST, CLP) do { \
+      allowDynamicLds((const void*)EAM_Force_cta_brick<STP, TAB, SPL, LST, CLP>, lds); \
+      hipLaunchKernelGGL((EAM_Force_cta_brick<STP, TAB, SPL, LST, CLP>), dim3(grid), dim3(64 * waves), lds, st, a, b); } while (0)
+#define COMD_LAUNCH_EAM_BRICK_C(STP, TAB, LST) do { if (clampFree) COMD_LAUNCH_EAM_BRICK(STP, TAB, false, LST, false); else COMD_LAUNCH_EAM_BRICK(STP, TAB, false, LST, true); } while (0)
+   if (STEP == 0)        COMD_LAUNCH_EAM_BRICK(0, false, false, true, true);
    else if (listed) {
-      if (spline)           COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, true, true);
-      else if (tablesInLds) COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), true, false, true);
-      else                  COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, false, true);
+      if (spline)           COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, true, true, true);
+      else if (tablesInLds) COMD_LAUNCH_EAM_BRICK_C((STEP == 0 ? 1 : STEP), true, true);
+      else                  COMD_LAUNCH_EAM_BRICK_C((STEP == 0 ? 1 : STEP), false, true);
    } else {
-      if (spline)           COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, true, false);
-      else if (tablesInLds) COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), true, false, false);
-      else                  COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, false, false);
+      if (spline)           COMD_LAUNCH_EAM_BRICK((STEP == 0 ? 1 : STEP), false, true, false, true);
+      else if (tablesInLds) COMD_LAUNCH_EAM_BRICK_C((STEP == 0 ? 1 : STEP), true, false);
+      else                  COMD_LAUNCH_EAM_BRICK_C((STEP == 0 ? 1 : STEP), false, false);
    }
+#undef COMD_LAUNCH_EAM_BRICK_C
 #undef COMD_LAUNCH_EAM_BRICK
    LAUNCH_CHECK();
 }

@@ -136,10 +136,12 @@ __device__ __forceinline__ TableView makeTable(const InterpolationObjectGpu& t, 
    return tv;
 }
 
+// CLAMP = false: the caller guarantees x0 <= r <= xn (the brick kernel's pairs: 0 < r <= cutoff, with tables that start at or below 0 and reach the cutoff --
+// the two clamps and the NaN-quieting moves hipcc puts in front of them are then dead weight: 4 of ~45 instructions per pair)
+template <bool CLAMP = true>
 __device__ __forceinline__ void interpolate(const TableView& t, real_t r, real_t& f, real_t& df)
 {
-   r = maxR(r, t.x0);
-   r = minR(r, t.xn);
+   if (CLAMP) { r = maxR(r, t.x0); r = minR(r, t.xn); }
    r = r * t.invDx - t.invDxXx0;
    real_t ri = floorR(r);
    int ii = (int)ri;
@@ -152,11 +154,11 @@ __device__ __forceinline__ void interpolate(const TableView& t, real_t r, real_t
 
 // phi(r) and rho(r) tabulated on the SAME grid (funcfl files are): values interleaved {phi_i, rho_i} so one index
 // computation and four 16-byte LDS reads serve both interpolations.  v[2*i], v[2*i+1]; i = 0 is the leading pad.
+template <bool CLAMP = true>
 __device__ __forceinline__ void interpolatePair(const real_t* __restrict__ v, const TableView& t, real_t r,
                                                 real_t& phi, real_t& dphi, real_t& rho, real_t& drho)
 {
-   r = maxR(r, t.x0);
-   r = minR(r, t.xn);
+   if (CLAMP) { r = maxR(r, t.x0); r = minR(r, t.xn); }
    r = r * t.invDx - t.invDxXx0;
    const real_t ri = floorR(r);
    const int ii = (int)ri;

@@ -100,7 +100,7 @@ void ClassifyBrickCells(EamBrickArgs b, const int* __restrict__ marks, int tag, 
    brickClass[bid] = any ? 1 : 2;
 }
 
-template <int STEP, bool LDS_TABLES, bool SPLINE, bool LISTED>
+template <int STEP, bool LDS_TABLES, bool SPLINE, bool LISTED, bool CLAMP>
 __global__ __launch_bounds__(256, 4)
 void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
 {
@@ -503,12 +503,12 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
                const real_t d0 = s0 * ir0, d1 = s1 * ir1;
                if (STEP == 1) {
                   real_t phi0, phi1;
-                  if (sameGrid) { interpolatePair(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
-                  else { interpolate(rhoT, d0, rho0, drho0); interpolate(phiT, d0, phi0, dphi0); interpolate(rhoT, d1, rho1, drho1); interpolate(phiT, d1, phi1, dphi1); }
+                  if (sameGrid) { interpolatePair<CLAMP>(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair<CLAMP>(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
+                  else { interpolate<CLAMP>(rhoT, d0, rho0, drho0); interpolate<CLAMP>(phiT, d0, phi0, dphi0); interpolate<CLAMP>(rhoT, d1, rho1, drho1); interpolate<CLAMP>(phiT, d1, phi1, dphi1); }
                   if (LISTED) { e = fmaR(phi0, w0, e); e = fmaR(phi1, w1, e); rb = fmaR(rho0, w0, rb); rb = fmaR(rho1, w1, rb); }
                   else { e += phi0 + (h1 ? phi1 : R(0.0)); rb += rho0 + (h1 ? rho1 : R(0.0)); }
                } else {
-                  interpolate(rhoT, d0, rho0, drho0); interpolate(rhoT, d1, rho1, drho1);
+                  interpolate<CLAMP>(rhoT, d0, rho0, drho0); interpolate<CLAMP>(rhoT, d1, rho1, drho1);
                   dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
                }
                if (LISTED) { dphi0 = dphi0 * (ir0 * w0); dphi1 = dphi1 * (ir1 * w1); }
