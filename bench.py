@@ -145,13 +145,14 @@ def profiled(pot, method, nx):
 
 KERNEL_SOURCES = {("lj", "thread_atom"): ["lj_kernels.h"], ("lj", "cta_cell"): ["lj_kernels.h"], ("lj", "cta_cell_pairlist"): ["lj_kernels.h"], ("lj", "thread_atom_nl"): ["nl_kernels.h"],
                   ("eam", "cta_cell"): ["eam_brick_kernels.h"], ("eam", "thread_atom_nl"): ["eam_brick_kernels.h"], ("eam", "thread_atom"): ["eam_kernels.h"]}
+COMMON_SOURCES = ["device_common.h"]              # (interpolate(), the reciprocal square root, the lane reductions: part of every force kernel)
 
 
 def kernel_source_hash(pot, method):
     """sha256 (first 16 hex digits) of the header(s) that hold the force kernel of this path: what a stored PMC record is valid for."""
     import hashlib
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES[(pot, method)]:
+    for name in KERNEL_SOURCES[(pot, method)] + COMMON_SOURCES:
         h.update(open(os.path.join(ROOT, "comd-cuda-async_amd", "csrc", "hip", name), "rb").read())
     return h.hexdigest()[:16]
 
