@@ -52,7 +52,7 @@ FORCE_FLOP_LISTED = {"lj": 2350 * 8 + 550 * 25}
 FORCE_FLOP_NL = {"lj": 732 * 8 + 550 * 25, "eam": 2 * (57 * 8 + 42 * 70)}
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4.0                 # wave-instructions/s the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per fp64 wave-instruction
 KERNEL_NAME = {("lj", "thread_atom"): "LJ_Force_thread_atom", ("lj", "cta_cell"): "LJ_Force_cta_cell_boxes", ("lj", "thread_atom_nl"): "LJ_Force_nl_slabs", ("lj", "cta_cell_pairlist"): "LJ_Force_cta_cell",
-               ("eam", "thread_atom"): "EAM_Force_thread_atom", ("eam", "cta_cell"): "EAM_Force_cta_brick<1> + <3>",
+               ("eam", "thread_atom"): "EAM_Force_atom_brick<1> + <3>", ("eam", "cta_cell"): "EAM_Force_cta_brick<1> + <3>",
                ("eam", "thread_atom_nl"): "EAM_Force_cta_brick<1, listed> + <3, listed> (Verlet rows)"}
 
 
@@ -144,7 +144,7 @@ def profiled(pot, method, nx):
 
 
 KERNEL_SOURCES = {("lj", "thread_atom"): ["lj_kernels.h"], ("lj", "cta_cell"): ["lj_kernels.h"], ("lj", "cta_cell_pairlist"): ["lj_kernels.h"], ("lj", "thread_atom_nl"): ["nl_kernels.h"],
-                  ("eam", "cta_cell"): ["eam_brick_kernels.h"], ("eam", "thread_atom_nl"): ["eam_brick_kernels.h"], ("eam", "thread_atom"): ["eam_kernels.h"]}
+                  ("eam", "cta_cell"): ["eam_brick_kernels.h"], ("eam", "thread_atom_nl"): ["eam_brick_kernels.h"], ("eam", "thread_atom"): ["eam_atom_brick_kernels.h"]}
 COMMON_SOURCES = ["device_common.h"]              # (interpolate(), the reciprocal square root, the lane reductions: part of every force kernel)
 
 

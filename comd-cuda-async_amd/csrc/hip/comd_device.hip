@@ -18,6 +18,7 @@
 #include "step_kernels.h"
 #include "nl_kernels.h"
 #include "eam_brick_kernels.h"
+#include "eam_atom_brick_kernels.h"
 
 static int g_rank = 0;
 
@@ -852,7 +853,7 @@ static void eamBrickGeometry(SimGpu* sim, bool listed, EamBrickArgs* b)
 // thread-per-atom form (correct, many times slower), so the occupancies are read once, the fullest block of this brick shape is found and the image
 // sized for it + 1 % + 8 (blocks gain or lose a handful of atoms through their surface as the lattice moves).  Both passes use that size.
 // Called by the first launch; by every Verlet-list build (the cells were just re-binned); and again when comdEamBrickStats finds bricks in the fall-back.
-static void eamBrickSizeImage(SimGpu* sim, const EamBrickArgs& b, hipStream_t st, bool listed)
+static int eamBrickSizeImage(SimGpu* sim, const EamBrickArgs& b, hipStream_t st, bool listed)
 {
    const double cellVol = 1.0 / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);
    const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
@@ -885,7 +886,7 @@ static void eamBrickSizeImage(SimGpu* sim, const EamBrickArgs& b, hipStream_t st
    if (cap < 256) cap = 256;
    if (cap > 4096) cap = 4096;                            // 16-bit numbers would reach 65535; beyond 4096 records the cells take the thread-per-atom form
    { const char* e = getenv("COMD_EAM_IMAGE"); if (e && atoi(e) >= 64) cap = (atoi(e) + 7) / 8 * 8; }      // experiments / tests: force the fallback
-   sim->eam_pot.brickImageCap = cap;
+   return cap;
 }
 
 // Verlet rows: the brick lists of a list build.  The occupancies are final (the atom exchange has run) and frozen until the next build, so the host can
@@ -995,7 +996,7 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    EamBrickArgs b;
    eamBrickGeometry(sim, listed, &b);
    const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
-   if (!sim->eam_pot.brickImageCap) eamBrickSizeImage(sim, b, st, listed);
+   if (!sim->eam_pot.brickImageCap) sim->eam_pot.brickImageCap = eamBrickSizeImage(sim, b, st, listed);
    b.imageCap = sim->eam_pot.brickImageCap;
    if (!sim->eam_pot.brickStats) sim->eam_pot.brickStats = dalloc<int>(2);
    b.stats = sim->eam_pot.brickStats;
@@ -1104,17 +1105,103 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
    LAUNCH_CHECK();
 }
 
+// thread_atom on the brick image (eam_atom_brick_kernels.h).  COMD_EAM_THREAD_ATOM=cell keeps round 2's kernel (a share of a wave per cell, candidates streamed
+// through L2; A/B runs), as do arrays of 4 GiB or more (the staging uses 32-bit byte offsets).
+static bool eamAtomBrickPath(const SimGpu* sim, int method)
+{
+   return (method == THREAD_ATOM || method == WARP_ATOM) && !(getenv("COMD_EAM_THREAD_ATOM") && !strcmp(getenv("COMD_EAM_THREAD_ATOM"), "cell"))
+          && (double)sim->boxes.nTotalBoxes * sim->maxAtoms * sizeof(real_t) < 4294967296.0;
+}
+
+template <int STEP>
+static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* cells_list, hipStream_t st, int spline)
+{
+   const size_t tableBytes = eamCtaTableBytes(STEP, a.rho.n, a.phi.n);
+   const bool tablesInLds = !spline && tableBytes <= 32 * 1024;
+   const bool sameGrid = a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+   auto tableDoublesOf = [&](int step) -> size_t {
+      if (!tablesInLds) return 0;
+      return step == 1 ? (size_t)2 * (a.rho.n + 3) + (sameGrid ? 0 : (a.phi.n + 3 - (a.rho.n + 3))) : (size_t)(a.rho.n + 3);
+   };
+   const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
+   const double rc = sim->eam_pot.cutoff;
+   // a row per thread: the cutoff sphere at the lattice's density + 50 %, a multiple of 8 (an atom with more neighbours walks its stencil a second time)
+   int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
+   if (rows < 32) rows = 32;
+   if (rows > 128) rows = 128;
+   EamBrickArgs b;
+   eamBrickGeometry(sim, false, &b);
+   const double perCell = 4.0 / (lat * lat * lat) / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);      // atoms of a cell at the lattice's density
+   // the threads that take atoms: whole waves for the brick's atoms + 8 % (a fuller brick's threads take a second atom)
+   auto rowThreadsOf = [&](double atoms) { int t = ((int)(atoms * 1.08) + 63) / 64 * 64; return t < 64 ? 64 : t > EAM_ATOM_BRICK_THREADS ? EAM_ATOM_BRICK_THREADS : t; };
+   // The brick: as many atoms as the workgroup has threads, the block within the 128 cells the staging covers, two workgroups per CU (80 KB of LDS each) in
+   // both passes.  Tried in this order; COMD_EAM_ATOM_BRICK="by,bz" overrides.  Fixed by the first launch, the image is sized again when bricks outgrow it.
+   if (!sim->eam_pot.atomBrickBy || !sim->eam_pot.atomBrickImageCap) {
+      static const int shapes[][2] = { { 4, 4 }, { 4, 3 }, { 4, 2 }, { 2, 2 }, { 2, 1 }, { 1, 1 } };
+      int ey = 0, ez = 0;
+      { const char* e = getenv("COMD_EAM_ATOM_BRICK"); if (!(e && sscanf(e, "%d,%d", &ey, &ez) == 2 && ey >= 1 && ez >= 1 && 3 * (ey + 2) * (ez + 2) <= EAM_BRICK_MAX_CELLS && ey * ez <= 64)) ey = ez = 0; }
+      const int nShapes = (int)(sizeof shapes / sizeof shapes[0]);
+      for (int k = sim->eam_pot.atomBrickBy ? nShapes - 1 : 0; k < nShapes; ++k) {
+         if (sim->eam_pot.atomBrickBy) { b.by = sim->eam_pot.atomBrickBy; b.bz = sim->eam_pot.atomBrickBz; }      // (re-sizing: the shape stays)
+         else if (ey) { b.by = ey; b.bz = ez; }
+         else { b.by = shapes[k][0]; b.bz = shapes[k][1]; }
+         b.nby = ceilDiv(b.geom.g[1], b.by); b.nbz = ceilDiv(b.geom.g[2], b.bz);
+         const int cap = eamBrickSizeImage(sim, b, st, false);
+         const bool last = ey || sim->eam_pot.atomBrickBy || k == nShapes - 1;
+         const int rt = rowThreadsOf(perCell * b.by * b.bz);
+         const size_t lds1 = eamAtomBrickLdsBytes(1, tableDoublesOf(1), cap, rows, rt), lds3 = eamAtomBrickLdsBytes(3, tableDoublesOf(3), cap, rows, rt);
+         if (last || (perCell * b.by * b.bz <= 1.05 * EAM_ATOM_BRICK_THREADS && lds1 <= 80 * 1024 && lds3 <= 80 * 1024)) {
+            sim->eam_pot.atomBrickBy = b.by; sim->eam_pot.atomBrickBz = b.bz; sim->eam_pot.atomBrickImageCap = cap;
+            break;
+         }
+      }
+   }
+   b.by = sim->eam_pot.atomBrickBy; b.bz = sim->eam_pot.atomBrickBz;
+   b.nby = ceilDiv(b.geom.g[1], b.by); b.nbz = ceilDiv(b.geom.g[2], b.bz);
+   b.imageCap = sim->eam_pot.atomBrickImageCap;
+   b.rows = rows;
+   b.listRounds = rowThreadsOf(perCell * b.by * b.bz);      // (EAM_Force_atom_brick reads its row threads here)
+   if (!sim->eam_pot.brickStats) sim->eam_pot.brickStats = dalloc<int>(2);
+   b.stats = sim->eam_pot.brickStats;
+   b.fuseEmbed = 0; b.status = sim->status;
+   { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
+   if (cells_list) {      // a launch over a cell list: mark the cells, every brick looks at its own (zeroed on the launch stream, see launchEamBrick)
+      if (!sim->eam_pot.cellSel) {
+         sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
+         HIP_CHECK(hipMemsetAsync(sim->eam_pot.cellSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(int), st));
+      }
+      b.sel = sim->eam_pot.cellSel; b.tag = ++sim->eam_pot.selTag;
+      ForceTimer aux(sim, st, 1);
+      hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(num_cells, 256)), dim3(256), 0, st, cells_list, num_cells, sim->eam_pot.cellSel, b.tag);
+   }
+   const size_t lds = eamAtomBrickLdsBytes(STEP, tableDoublesOf(STEP), b.imageCap, b.rows, b.listRounds);
+   if (lds > 160 * 1024) { fprintf(stderr, "eamForce: thread_atom needs %zu bytes of LDS for this box\n", lds); exit(-1); }
+   const int grid = b.geom.g[0] * b.nby * b.nbz;
+   if (grid <= 0) return;
+   const double rcut = sim->eam_pot.cutoff * (1.0 + 4e-16);      // (as launchEamBrick: the table clamps are dead weight when every evaluated pair lies inside the tables)
+   const bool clampFree = !spline && a.phi.x0 <= R(0.0) && a.rho.x0 <= R(0.0) && rcut <= (double)a.phi.xn && rcut <= (double)a.rho.xn
+                          && !(getenv("COMD_EAM_CLAMP") && atoi(getenv("COMD_EAM_CLAMP")) != 0);
+#define COMD_LAUNCH_EAM_ATOM_BRICK(TAB, SPL, CLP) do { \
+      allowDynamicLds((const void*)EAM_Force_atom_brick<STEP, TAB, SPL, CLP>, lds); \
+      hipLaunchKernelGGL((EAM_Force_atom_brick<STEP, TAB, SPL, CLP>), dim3(grid), dim3(EAM_ATOM_BRICK_THREADS), lds, st, a, b); } while (0)
+   if (spline)           COMD_LAUNCH_EAM_ATOM_BRICK(false, true, true);
+   else if (tablesInLds) { if (clampFree) COMD_LAUNCH_EAM_ATOM_BRICK(true, false, false); else COMD_LAUNCH_EAM_ATOM_BRICK(true, false, true); }
+   else                  { if (clampFree) COMD_LAUNCH_EAM_ATOM_BRICK(false, false, false); else COMD_LAUNCH_EAM_ATOM_BRICK(false, false, true); }
+#undef COMD_LAUNCH_EAM_ATOM_BRICK
+   LAUNCH_CHECK();
+}
+
 // cta_cell: size the brick image again at the next launch (between two force evaluations only: pass 1 and pass 3 of one evaluation must stage alike)
-extern "C" void comdEamBrickResize(SimGpu* sim) { sim->eam_pot.brickImageCap = 0; }
+extern "C" void comdEamBrickResize(SimGpu* sim) { sim->eam_pot.brickImageCap = 0; sim->eam_pot.atomBrickImageCap = 0; }
 
 // what the force wrappers decided for this simulation (bench.py records it beside the numbers): {LJ thread_atom candidate lists in use (0: the 27-cell walk),
 // records of the EAM brick image, Verlet-list format (comd_hip.h slabFormat), cells per EAM brick}
 extern "C" void comdForcePathInfo(SimGpu* sim, int out[4])
 {
    out[0] = sim->lj_pot.packedCap > 0 ? 1 : 0;
-   out[1] = sim->eam_pot.brickImageCap;
+   out[1] = sim->eam_pot.brickImageCap ? sim->eam_pot.brickImageCap : sim->eam_pot.atomBrickImageCap;
    out[2] = sim->atoms.neighborList.slabFormat;
-   out[3] = sim->eam_pot.brickBy * sim->eam_pot.brickBz + 256 * sim->eam_pot.brickListMakes;      // (cells per brick in the low byte, times the brick lists were made above)
+   out[3] = (sim->eam_pot.brickBy ? sim->eam_pot.brickBy * sim->eam_pot.brickBz : sim->eam_pot.atomBrickBy * sim->eam_pot.atomBrickBz) + 256 * sim->eam_pot.brickListMakes;      // (cells per brick in the low byte, times the brick lists were made above)
 }
 
 extern "C" void comdEamBrickStats(SimGpu* sim, int out[3])
@@ -1125,8 +1212,10 @@ extern "C" void comdEamBrickStats(SimGpu* sim, int out[3])
    HIP_CHECK(hipDeviceSynchronize());
    HIP_CHECK(hipMemcpy(h, sim->eam_pot.brickStats, sizeof h, hipMemcpyDeviceToHost));
    HIP_CHECK(hipMemset(sim->eam_pot.brickStats + 1, 0, sizeof(int)));
-   int by = sim->eam_pot.brickBy ? sim->eam_pot.brickBy : 4, bz = sim->eam_pot.brickBz ? sim->eam_pot.brickBz : 2;
-   out[0] = h[1]; out[1] = sim->boxes.gridSize[0] * ceilDiv(sim->boxes.gridSize[1], by) * ceilDiv(sim->boxes.gridSize[2], bz); out[2] = sim->eam_pot.brickImageCap;
+   const bool atomBrick = !sim->eam_pot.brickBy && sim->eam_pot.atomBrickBy;      // (thread_atom on the brick image: its shape, its image)
+   int by = atomBrick ? sim->eam_pot.atomBrickBy : sim->eam_pot.brickBy ? sim->eam_pot.brickBy : 4, bz = atomBrick ? sim->eam_pot.atomBrickBz : sim->eam_pot.brickBz ? sim->eam_pot.brickBz : 2;
+   out[0] = h[1]; out[1] = sim->boxes.gridSize[0] * ceilDiv(sim->boxes.gridSize[1], by) * ceilDiv(sim->boxes.gridSize[2], bz);
+   out[2] = atomBrick ? sim->eam_pot.atomBrickImageCap : sim->eam_pot.brickImageCap;
 }
 
 template <int STEP>
@@ -1138,10 +1227,14 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
    if (spline) {
       // -P (gpu_kernels.cu:164-226): cubic splines in r^2 for phi and rho, coefficient tables read through L2 (16 KB each for funcfl)
       if (!a.phiS.coefficients || !a.rhoS.coefficients) { fprintf(stderr, "eamForce: spline != 0 but no spline tables were given to AllocateGpu\n"); exit(-1); }
-      if (method == THREAD_ATOM || method == WARP_ATOM) {
+      if ((method == THREAD_ATOM || method == WARP_ATOM) && !eamAtomBrickPath(sim, method)) {
          launchEamThreadAtom<STEP>(sim, a, num_cells, st, true);
          return;
       }
+   }
+   if (eamAtomBrickPath(sim, method)) {
+      launchEamAtomBrick<STEP>(sim, a, num_cells, cells_list, st, spline);
+      return;
    }
    if (eamListedBrick(sim, method)) {
       if (sim->atoms.neighborList.nBuilds == 0) { fprintf(stderr, "the *_nl methods need buildNeighborListGpu before the first force call\n"); exit(-1); }

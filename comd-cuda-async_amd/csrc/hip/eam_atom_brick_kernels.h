@@ -1,0 +1,351 @@
+// eam_atom_brick_kernels.h -- EAM_Force_atom_brick: the thread-per-atom EAM kernel (method thread_atom, passes 1 and 3) with the brick image as its staging.
+//
+// Physics and results of the reference's EAM_Force_thread_atom<step> (gpu_eam_thread_atom.h:32-140): one THREAD owns one atom from the first candidate to the
+// stores.  What round 2's kernel of that shape (eam_kernels.h) paid for was the walk: every thread streamed the 283 atoms of its 27-cell stencil from L2 and
+// evaluated under divergence with one lane in seven inside the cutoff.  Here
+//   * a workgroup owns a brick of 1 x BY x BZ link cells (default 1 x 4 x 4) and stages the 3 x (BY + 2) x (BZ + 2) cells around it ONCE into the LDS, densely
+//     packed, z-y-x order (the staging of eam_brick_kernels.h: the stencil of a cell is three contiguous runs of records);
+//   * thread t takes the brick's t-th atom and works in two phases.  TEST: walk the three runs of its cell's stencil -- lanes of one cell read the same record
+//     (an LDS broadcast) -- and append the numbers of the records inside the cutoff to a row of its own in the LDS (16-bit numbers, 132-byte stride: the rows of
+//     a wave's lanes start on distinct banks).  EVALUATE: walk that row, two pairs per trip, branch-free inside the trip.  The divergence that is left is the
+//     row LENGTH (42 +- a few at 80^3), not the acceptance rate;
+//   * nothing is handed from pass 1 to pass 3: pass 3 tests again (the rows of 2 M atoms would cost a 260 MB round trip through HBM for 40 % of one pass), so
+//     a launch over any cell list is complete in itself and the two passes need not agree on anything.
+// A brick whose block outgrows the image takes the streaming form (eamCellDirect, a wave per cell) -- counted in stats[1], the host re-sizes the image.
+#pragma once
+#include "eam_brick_kernels.h"
+
+#define EAM_ATOM_BRICK_THREADS 256
+
+// a thread's row: `rows` numbers + 6 of padding (a group of four candidates is appended before the row's end is looked at; an odd count of dwords for rows % 8 == 0)
+__host__ __device__ static inline int eamAtomBrickRowStride(int rows) { return rows + 6; }
+// LDS of one workgroup: tables | image (+ F' in pass 3) | offsets, cell ids, scalars, selected cells (eamBrickSharedBytes) | own-atom prefix | rows
+// (rowThreads: the threads that take atoms -- whole waves, enough for the brick's atoms; EamBrickArgs.listRounds carries the number to the kernel.  The
+// other waves of the 256 only help to stage: rows for threads that never have an atom would cost the second workgroup of a CU.)
+static inline size_t eamAtomBrickLdsBytes(int step, size_t tableDoubles, int imageCap, int rows, int rowThreads)
+{
+   return eamTableBytesAligned(tableDoubles) + eamBrickSharedBytes(step, imageCap) + 68 * sizeof(int)
+          + (size_t)rowThreads * eamAtomBrickRowStride(rows) * sizeof(unsigned short);
+}
+
+template <int STEP, bool LDS_TABLES, bool SPLINE, bool CLAMP>
+__global__ __launch_bounds__(EAM_ATOM_BRICK_THREADS, 2)
+void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
+{
+   static_assert(STEP == 1 || STEP == 3, "passes 1 and 3");
+   extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+   constexpr int REC = 3, SLOT_BITS = 4, SLOTS = 1 << SLOT_BITS, STAGE = EAM_BRICK_STAGE;
+   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), nThreads = EAM_ATOM_BRICK_THREADS, nWaves = nThreads >> 6;
+   const int nRhoPad = a.rho.n + 3;
+   const bool sameGrid = (STEP == 1) && LDS_TABLES && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
+   real_t* sRho = (real_t*)ldsRaw;
+   real_t* sPhi = sRho + nRhoPad;
+   int tableDoubles = 0;
+   if (LDS_TABLES) tableDoubles = (STEP == 1) ? 2 * nRhoPad + (sameGrid ? 0 : (a.phi.n + 3 - nRhoPad)) : nRhoPad;
+
+   real_t* __restrict__ sp = (real_t*)(ldsRaw + eamTableBytesAligned(tableDoubles));
+   real_t* __restrict__ sd = sp + REC * b.imageCap;          // [imageCap] F' (pass 3)
+   int* sOff = (int*)(ldsRaw + eamTableBytesAligned(tableDoubles) + ((((size_t)(STEP == 3 ? 4 : 3) * b.imageCap * sizeof(real_t)) + 15) & ~(size_t)15));
+   int* sBox = sOff + EAM_BRICK_MAX_CELLS + 4;               // [128] cell ids of the block
+   int* sMisc = sBox + EAM_BRICK_MAX_CELLS;                  // [16]: 0/1 selection mask, 4 records in the image
+   unsigned char* sList = (unsigned char*)(sMisc + 16);      // [64] selected cells of the brick, compacted
+   int* sOwn = (int*)(sList + 64);                           // [65] atoms of the selected cells before cell k of that list
+   const int strideL = eamAtomBrickRowStride(b.rows);
+   unsigned short* __restrict__ myRow = (unsigned short*)(sOwn + 68) + (size_t)tid * strideL;
+
+   // ---- the brick and its selected cells (as EAM_Force_cta_brick) ---------------------------------------------------------------------------
+   const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2];
+   const int bid = xcdRemap(blockIdx.x, gridDim.x);          // x fastest: consecutive bricks share two thirds of their block
+   const int bx = bid % gx, by0 = ((bid / gx) % b.nby) * b.by, bz0 = (bid / (gx * b.nby)) * b.bz;
+   const int HY = b.by + 2, HZ = b.bz + 2, NH = 3 * HY * HZ, NC = b.by * b.bz;
+   unsigned long long selMask;
+   if (b.sel) {      // a launch over a cell list: the marks of the brick's cells
+      if (wave == 0) {
+         bool s = false;
+         if (lane < NC) {
+            const int iy = by0 + lane % b.by, iz = bz0 + lane / b.by;
+            if (iy < gy && iz < gz) s = b.sel[comdBoxFromTuple(&b.geom, bx, iy, iz)] == b.tag;
+         }
+         const unsigned long long m = __builtin_amdgcn_ballot_w64(s);
+         if (lane == 0) { sMisc[0] = (int)(unsigned)m; sMisc[1] = (int)(unsigned)(m >> 32); }
+      }
+      __syncthreads();
+      selMask = ((unsigned long long)(unsigned)uniform(sMisc[1]) << 32) | (unsigned)uniform(sMisc[0]);
+      if (selMask == 0ull) return;
+   } else {
+      bool s = false;
+      if (lane < NC) s = by0 + lane % b.by < gy && bz0 + lane / b.by < gz;
+      selMask = __builtin_amdgcn_ballot_w64(s);
+   }
+   const int nSel = __popcll(selMask);
+   if (wave == 0) {
+      const bool s = (selMask >> lane) & 1ull;
+      if (s) sList[__builtin_amdgcn_mbcnt_hi((unsigned)(selMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)selMask, 0u))] = (unsigned char)lane;
+   }
+
+   // ---- ONE round trip for the block: occupancies and records are requested together (slot s of block cell h = task SLOTS h + s) ---------------
+   real_t lx[STAGE], ly[STAGE], lz[STAGE], ld[STAGE];
+   bool lok[STAGE];
+   int myBox = -1;
+   auto request = [&](const int k, const int bb, const int s) {      // (32-bit byte offsets: the launcher sends arrays of 4 GiB or more to the other kernel)
+      lok[k] = bb >= 0 && s < a.cap;
+      lx[k] = ly[k] = lz[k] = ld[k] = R(0.0);
+      if (lok[k]) {
+         const unsigned o = ((unsigned)bb * (unsigned)a.cap + (unsigned)s) * (unsigned)sizeof(real_t);
+         lx[k] = *reinterpret_cast<const real_t*>(reinterpret_cast<const char*>(a.rx) + o);
+         ly[k] = *reinterpret_cast<const real_t*>(reinterpret_cast<const char*>(a.ry) + o);
+         lz[k] = *reinterpret_cast<const real_t*>(reinterpret_cast<const char*>(a.rz) + o);
+         if (STEP == 3) ld[k] = *reinterpret_cast<const real_t*>(reinterpret_cast<const char*>(a.dfEmbed) + o);
+      }
+   };
+   // every wave works out the cell ids of all 128 block cells (two per lane; -1: outside the grid or in no selected cell's stencil -- a launch over the
+   // interior cells runs while the halo cells are being filled and must not look at them)
+   auto blockBox = [&](const int h) {
+      int box = -1;
+      if (h < NH) {
+         const int xh = h % 3, yh = (h / 3) % HY, zh = h / (3 * HY);
+         const int iy = by0 + yh - 1, iz = bz0 + zh - 1;
+         if (iy <= gy && iz <= gz) {
+            bool need = false;
+#pragma unroll
+            for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+               for (int dy = -1; dy <= 1; ++dy) {
+                  const int cy = yh - 1 + dy, cz = zh - 1 + dz;
+                  if (cy >= 0 && cy < b.by && cz >= 0 && cz < b.bz) need = need || ((selMask >> (cy + b.by * cz)) & 1ull);
+               }
+            if (need) box = comdBoxFromTuple(&b.geom, bx + xh - 1, iy, iz);
+         }
+      }
+      return box;
+   };
+   const int boxLo = blockBox(lane), boxHi = blockBox(64 + lane);
+   if (wave < 2) myBox = wave == 0 ? boxLo : boxHi;
+#pragma unroll
+   for (int k = 0; k < STAGE; ++k) {
+      const int task = k * nThreads + tid, h = task >> SLOT_BITS;
+      const int fromLo = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxLo), fromHi = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxHi);
+      request(k, h < NH ? (h < 64 ? fromLo : fromHi) : -1, task & (SLOTS - 1));
+   }
+   int myCnt = 0;
+   if (myBox >= 0) myCnt = a.nAtoms[myBox];
+   if (LDS_TABLES) {
+      if (sameGrid) {
+         for (int t = tid; t < nRhoPad; t += nThreads) { sRho[2 * t] = a.phi.values[t]; sRho[2 * t + 1] = a.rho.values[t]; }
+      } else {
+         for (int t = tid; t < nRhoPad; t += nThreads) sRho[t] = a.rho.values[t];
+         if (STEP == 1) for (int t = tid; t < a.phi.n + 3; t += nThreads) sPhi[t] = a.phi.values[t];
+      }
+   }
+   const TableView rhoT = makeTable(a.rho, LDS_TABLES ? sRho : a.rho.values), phiT = makeTable(a.phi, LDS_TABLES ? sPhi : a.phi.values);
+   if (tid < EAM_BRICK_MAX_CELLS) { sBox[tid] = myBox >= 0 ? myBox : 0; sOff[tid] = myCnt; }
+   __syncthreads();
+   if (wave == 0) {                                          // exclusive scan of the 128 counts: lane l takes entries 2l and 2l + 1
+      const int c0 = sOff[2 * lane], c1 = sOff[2 * lane + 1];
+      int incl = c0 + c1;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+      const int excl = incl - c0 - c1;
+      sOff[2 * lane] = excl; sOff[2 * lane + 1] = excl + c0;
+      if (lane == 63) { sOff[EAM_BRICK_MAX_CELLS] = incl; sMisc[4] = incl; }
+      // the brick's own atoms, cell after cell of the selection: lane k = the k-th selected cell
+      __builtin_amdgcn_wave_barrier();
+      int own = 0;
+      if (lane < nSel) {
+         const int cl = sList[lane], hc = 1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1));
+         own = sOff[hc + 1] - sOff[hc];
+      }
+      int inclOwn = own;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inclOwn, d); if (lane >= d) inclOwn += up; }
+      sOwn[lane + 1] = inclOwn;
+      if (lane == 0) sOwn[0] = 0;
+   }
+   __syncthreads();
+   const int imageTotal = uniform(sMisc[4]);
+   const bool fits = imageTotal <= b.imageCap;
+   if (!fits) {      // a block larger than the LDS image: streaming form, a wave per cell, same tables
+      if (STEP == 1 && b.stats && tid == 0) atomicAdd(&b.stats[1], 1);
+      for (int pick = wave; pick < nSel; pick += nWaves) {
+         const int cl = sList[pick], hc = 1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1));
+         eamCellDirect<STEP, SPLINE>(a, uniform(sBox[hc]), lane, rhoT, phiT, sameGrid, b.fuseEmbed);
+      }
+      return;
+   }
+#pragma unroll
+   for (int k = 0; k < STAGE; ++k) {
+      const int task = k * nThreads + tid, h = task >> SLOT_BITS, s = task & (SLOTS - 1);
+      if (lok[k]) {
+         const int off = sOff[h], n = sOff[h + 1] - off;
+         if (s < n) {
+            real_t* r = sp + REC * (off + s);
+            r[0] = lx[k]; r[1] = ly[k]; r[2] = lz[k];
+            if (STEP == 3) sd[off + s] = ld[k];
+         }
+      }
+   }
+   // cells of more than SLOTS atoms: blocking copies
+   for (int task = tid; task < NH * SLOTS; task += nThreads) {
+      const int h = task >> SLOT_BITS, off = sOff[h], n = sOff[h + 1] - off;
+      for (int s = (task & (SLOTS - 1)) + SLOTS; s < n; s += SLOTS) {
+         const size_t o = (size_t)sBox[h] * a.cap + s;
+         real_t* r = sp + REC * (off + s);
+         r[0] = a.rx[o]; r[1] = a.ry[o]; r[2] = a.rz[o];
+         if (STEP == 3) sd[off + s] = a.dfEmbed[o];
+      }
+   }
+   __syncthreads();
+
+   if (b.debug & 4) return;
+   // ---- thread t takes own atom t, t + 256, ... ----------------------------------------------------------------------------------------------------
+   const int nOwn = uniform(sOwn[nSel]);
+   const int rowThreads = b.listRounds;                      // threads that take atoms (whole waves)
+   if ((wave << 6) >= rowThreads) return;
+   for (int base = wave << 6; base < nOwn; base += rowThreads) {      // (wave-uniform: a wave whose 64 atoms do not exist has nothing to do)
+      const bool have = base + lane < nOwn;
+      const int t = have ? base + lane : nOwn - 1;           // lanes past the last atom repeat it and store nothing: the walk below has wave-uniform parts
+      int k = 0;
+      for (int s = 1; s < nSel; ++s) k += t >= sOwn[s] ? 1 : 0;
+      const int cl = sList[k], yh = cl % b.by + 1, zh = cl / b.by + 1, hc = 1 + 3 * (yh + HY * zh);
+      const int iBox = sBox[hc], ia = t - sOwn[k], recI = sOff[hc] + ia;
+      const real_t xi = sp[REC * recI], yi = sp[REC * recI + 1], zi = sp[REC * recI + 2];
+      const real_t dfi = (STEP == 3) ? sd[recI] : R(0.0);
+
+      // TEST: the three runs of the cell's stencil (rows yh-1 .. yh+1 of a z plane lie back to back).  Four candidates per group, the records of the NEXT
+      // group requested before the current one is tested (two register sets, ping-pong): the walk lives on LDS latency, and a brick workgroup's waves are few.
+      // The groups every lane of the wave has whole are walked without masks, addresses as immediate offsets from one running pointer; what is left of the
+      // longer runs takes the masked form (a candidate past the end names the atom itself: no hit).  The row's end is looked at once per group (its padding takes the
+      // group).  Only the middle plane holds the atom itself.
+      unsigned short* w = myRow;
+      unsigned short* const wEnd = myRow + b.rows;
+      bool over = false;                                    // more hits than the row holds
+      constexpr int G = 4;
+#pragma unroll 1
+      for (int p = (b.debug & 1) ? 3 : 0; p < 3; ++p) {
+         const int rs = sOff[3 * ((yh - 1) + HY * (zh - 1 + p))], len = sOff[3 * ((yh + 1) + HY * (zh - 1 + p)) + 3] - rs;
+         real_t ax[G], ay[G], az[G], cx[G], cy[G], cz[G];
+         int whole = len / (2 * G);
+#pragma unroll
+         for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(whole, m); whole = o < whole ? o : whole; }
+         whole = uniform(whole);
+         int u = 0;
+         if (whole > 0) {
+            const real_t* __restrict__ q = sp + REC * rs;
+            auto askU = [&](const real_t* __restrict__ src, real_t (&X)[G], real_t (&Y)[G], real_t (&Z)[G]) {
+#pragma unroll
+               for (int g = 0; g < G; ++g) { X[g] = src[REC * g]; Y[g] = src[REC * g + 1]; Z[g] = src[REC * g + 2]; }
+            };
+            auto testU = [&](const int r0, const bool self, const real_t (&X)[G], const real_t (&Y)[G], const real_t (&Z)[G]) {
+#pragma unroll
+               for (int g = 0; g < G; ++g) {
+                  const real_t dx = xi - X[g], dy = yi - Y[g], dz = zi - Z[g];
+                  bool hit = dx * dx + dy * dy + dz * dz <= a.rc2;
+                  if (self) hit = hit && r0 + g != recI;
+                  *w = (unsigned short)(r0 + g);             // (unconditional: a candidate that is no hit is overwritten by the next; no exec-mask round trip per candidate)
+                  w += hit ? 1 : 0;
+               }
+               over = over || w > wEnd; w = w > wEnd ? wEnd : w;
+            };
+            askU(q, ax, ay, az);
+            if (p == 1) {
+               for (int it = 0; it < whole; ++it) {
+                  askU(q + REC * G, cx, cy, cz); testU(rs + u, true, ax, ay, az);
+                  askU(q + 2 * REC * G, ax, ay, az); testU(rs + u + G, true, cx, cy, cz);      // (the last request reads past the whole groups, inside the image or its neighbours in the LDS: dropped)
+                  q += 2 * REC * G; u += 2 * G;
+               }
+            } else {
+               for (int it = 0; it < whole; ++it) {
+                  askU(q + REC * G, cx, cy, cz); testU(rs + u, false, ax, ay, az);
+                  askU(q + 2 * REC * G, ax, ay, az); testU(rs + u + G, false, cx, cy, cz);
+                  q += 2 * REC * G; u += 2 * G;
+               }
+            }
+         }
+         auto ask = [&](const int v, real_t (&X)[G], real_t (&Y)[G], real_t (&Z)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+               const int r = v + g < len ? rs + v + g : recI;
+               X[g] = sp[REC * r]; Y[g] = sp[REC * r + 1]; Z[g] = sp[REC * r + 2];
+            }
+         };
+         auto test = [&](const int v, const real_t (&X)[G], const real_t (&Y)[G], const real_t (&Z)[G]) {
+#pragma unroll
+            for (int g = 0; g < G; ++g) {
+               const int r = v + g < len ? rs + v + g : recI;
+               const real_t dx = xi - X[g], dy = yi - Y[g], dz = zi - Z[g];
+               const bool hit = dx * dx + dy * dy + dz * dz <= a.rc2 && r != recI;
+               *w = (unsigned short)r;
+               w += hit ? 1 : 0;
+            }
+            over = over || w > wEnd; w = w > wEnd ? wEnd : w;
+         };
+         for (; u < len; u += G) { ask(u, ax, ay, az); test(u, ax, ay, az); }
+      }
+      int n = over ? b.rows + 1 : (int)(w - myRow);
+      // EVALUATE: two pairs per trip, branch-free; a missing second pair is evaluated at r = cutoff and weighted 0
+      real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0);
+      auto evalTrip = [&](const int j0, const int j1, const bool h1) {
+         const real_t* r0 = sp + REC * j0; const real_t* r1 = sp + REC * j1;
+         const real_t dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
+         const real_t dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
+         const real_t s0 = dx0*dx0 + dy0*dy0 + dz0*dz0;
+         const real_t s1 = h1 ? dx1*dx1 + dy1*dy1 + dz1*dz1 : a.rc2;
+         real_t rho0, drho0, dphi0, rho1, drho1, dphi1;
+         if (SPLINE) {                                       // -P: cubic splines in r^2 give (1/r) d/dr directly, no square root
+            interpolateSpline(a.rhoS, s0, rho0, drho0); interpolateSpline(a.rhoS, s1, rho1, drho1);
+            if (STEP == 1) {
+               real_t phi0, phi1;
+               interpolateSpline(a.phiS, s0, phi0, dphi0); interpolateSpline(a.phiS, s1, phi1, dphi1);
+               e += phi0 + (h1 ? phi1 : R(0.0)); rb += rho0 + (h1 ? rho1 : R(0.0));
+            } else {
+               dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
+            }
+            dphi1 = h1 ? dphi1 : R(0.0);
+         } else {
+            const real_t ir0 = rsqrtR(s0), ir1 = rsqrtR(s1);
+            const real_t d0 = s0 * ir0, d1 = s1 * ir1;
+            if (STEP == 1) {
+               real_t phi0, phi1;
+               if (sameGrid) { interpolatePair<CLAMP>(sRho, rhoT, d0, phi0, dphi0, rho0, drho0); interpolatePair<CLAMP>(sRho, rhoT, d1, phi1, dphi1, rho1, drho1); }
+               else { interpolate<CLAMP>(rhoT, d0, rho0, drho0); interpolate<CLAMP>(phiT, d0, phi0, dphi0); interpolate<CLAMP>(rhoT, d1, rho1, drho1); interpolate<CLAMP>(phiT, d1, phi1, dphi1); }
+               e += phi0 + (h1 ? phi1 : R(0.0)); rb += rho0 + (h1 ? rho1 : R(0.0));
+            } else {
+               interpolate<CLAMP>(rhoT, d0, rho0, drho0); interpolate<CLAMP>(rhoT, d1, rho1, drho1);
+               dphi0 = (dfi + sd[STEP == 3 ? j0 : 0]) * drho0; dphi1 = (dfi + sd[STEP == 3 ? j1 : 0]) * drho1;
+            }
+            dphi0 = dphi0 * ir0; dphi1 = h1 ? dphi1 * ir1 : R(0.0);
+         }
+         fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
+         fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
+      };
+      if (b.debug & 2) n = 0;
+      if (n <= b.rows) {
+         for (int u = 0; u < n; u += 2) {
+            const bool h1 = u + 1 < n;
+            evalTrip(myRow[u], h1 ? (int)myRow[u + 1] : recI, h1);
+         }
+      } else {
+         // more neighbours than a row holds (a density far above the lattice's): this atom walks its stencil again and evaluates as it goes -- thread_atom
+         // is the method without a limit
+#pragma unroll 1
+         for (int p = 0; p < 3; ++p) {
+            const int rs = sOff[3 * ((yh - 1) + HY * (zh - 1 + p))], re = sOff[3 * ((yh + 1) + HY * (zh - 1 + p)) + 3];
+#pragma unroll 1
+            for (int r = rs; r < re; ++r) {
+               const real_t ax = xi - sp[REC * r], ay = yi - sp[REC * r + 1], az = zi - sp[REC * r + 2];
+               if (ax * ax + ay * ay + az * az <= a.rc2 && r != recI) evalTrip(r, recI, false);
+            }
+         }
+      }
+      if (!have) continue;
+      const size_t iOff = (size_t)iBox * a.cap + ia;
+      if (STEP == 1) {
+         a.fx[iOff] = fx; a.fy[iOff] = fy; a.fz[iOff] = fz; a.rhobar[iOff] = rb;
+         real_t ei = R(0.5) * e;
+         if (b.fuseEmbed) { real_t F, dF; interpolate(makeTable(a.f, a.f.values), rb, F, dF); a.dfEmbed[iOff] = dF; ei += F; }
+         a.e[iOff] = ei;
+      } else {
+         a.fx[iOff] += fx; a.fy[iOff] += fy; a.fz[iOff] += fz;
+      }
+   }
+}

@@ -59,11 +59,11 @@ void kineticEnergyGpu(SimFlat* s)
    computeEnergy(&s->gpu, eLocal);
    comdCheckStatus(&s->gpu, "kineticEnergyGpu");      /* cell / message overflow and lost atoms surface here */
    if (s->gpu.do_eam) {
-      /* cta_cell: bricks whose block outgrew the LDS image took the thread-per-atom form (correct, many times slower).  The image was sized for the occupancies of
+      /* cta_cell, thread_atom: bricks whose block outgrew the LDS image took the thread-per-atom form (correct, many times slower).  The image was sized for the occupancies of
        * the first launch; a system that has changed since (heating, a density front) is noticed here, once per energy read, and the next launch sizes it again */
       int st[3];
       comdEamBrickStats(&s->gpu, st);
-      if (st[0] > 0 && s->method == CTA_CELL) {
+      if (st[0] > 0 && (s->method == CTA_CELL || s->method == THREAD_ATOM || s->method == WARP_ATOM)) {
          if (!s->quiet && printRank()) fprintf(stderr, "eamForce: %d brick launches took the thread-per-atom form since the last energy read (image of %d records): re-sizing the image\n", st[0], st[2]);
          comdEamBrickResize(&s->gpu);
       }

@@ -107,6 +107,9 @@ typedef struct EamPotentialGpuSt {
    unsigned long long* brickSel;       /* device [nLocalBoxes] */
    int*    brickStats;                 /* device [2]: {longest Verlet row of the last list build, bricks that took the thread-per-atom form since the last comdEamBrickStats} */
    int     brickBy, brickBz;           /* host: the brick shape of this simulation (fixed by the first launch: rows index the image of that shape) */
+   /* [round 4] method thread_atom (EAM_Force_atom_brick, hip/eam_atom_brick_kernels.h): thread per atom inside a brick workgroup; a shape and an image of its own */
+   int     atomBrickBy, atomBrickBz;   /* host: brick shape (0: chosen by the first launch) */
+   int     atomBrickImageCap;          /* host: records of its LDS image (0: sized by the next launch) */
 } EamPotentialGpu;
 
 /* gpu_types.h:98-112 */
