@@ -475,7 +475,7 @@ extern "C" void DestroyGpu(SimGpu* sim)
                     sim->atoms.neighborList.lastR.y, sim->atoms.neighborList.lastR.z,
                     sim->atoms.neighborList.list16, sim->atoms.neighborList.stats, sim->atoms.neighborList.pairlist,
                     sim->boxes.boxIDLookUp, sim->boxes.boxIDLookUpReverse, sim->eam_pot.phiS.coefficients, sim->eam_pot.rhoS.coefficients,
-                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->eam_pot.brickGroup, sim->eam_pot.brickList, sim->eam_pot.brickSel, sim->eam_pot.brickStats,
+                    sim->eam_pot.pairRows, sim->eam_pot.pairRowCount, sim->eam_pot.cellSel, sim->eam_pot.brickGroup, sim->eam_pot.brickList, sim->eam_pot.brickSel, sim->eam_pot.brickStats, sim->eam_pot.atomRows, sim->eam_pot.atomRowCount, sim->eam_pot.atomBrickSel,
                     sim->atoms.neighborList.brickRows, sim->atoms.neighborList.brickRowCount, sim->adapterScan, sim->lj_pot.waveCand, sim->lj_pot.waveCandCount, sim->lj_pot.packedR[0], sim->lj_pot.packedR[1], sim->lj_pot.packedF[0], sim->lj_pot.packedF[1] };
    for (void* p : ptrs) if (p) HIP_CHECK(hipFree(p));
    if (sim->statusEvent) (void)hipEventDestroy((hipEvent_t)sim->statusEvent);
@@ -1129,6 +1129,7 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
    if (rows < 32) rows = 32;
    if (rows > 128) rows = 128;
+   { const char* e = getenv("COMD_EAM_ATOM_ROWS"); if (e && atoi(e) >= 8 && atoi(e) <= 128) rows = atoi(e) / 8 * 8; }      // tests: rows that overflow
    EamBrickArgs b;
    eamBrickGeometry(sim, false, &b);
    const double perCell = 4.0 / (lat * lat * lat) / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);      // atoms of a cell at the lattice's density
@@ -1163,8 +1164,20 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    b.listRounds = rowThreadsOf(perCell * b.by * b.bz);      // (EAM_Force_atom_brick reads its row threads here)
    if (!sim->eam_pot.brickStats) sim->eam_pot.brickStats = dalloc<int>(2);
    b.stats = sim->eam_pot.brickStats;
-   b.fuseEmbed = 0; b.status = sim->status;
+   b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
    { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
+   // the rows pass 1 leaves for pass 3 (eam_atom_brick_kernels.h; COMD_EAM_ATOM_HANDOVER=0: pass 3 tests again, A/B runs)
+   if (!(getenv("COMD_EAM_ATOM_HANDOVER") && atoi(getenv("COMD_EAM_ATOM_HANDOVER")) == 0)) {
+      const size_t nBricks = (size_t)b.geom.g[0] * b.nby * b.nbz;
+      if (!sim->eam_pot.atomRows) {
+         sim->eam_pot.atomRows = dalloc<unsigned>(nBricks * (rows / 8) * 256 * 4, false);
+         sim->eam_pot.atomRowCount = dalloc<unsigned short>(nBricks * 256, false);
+         sim->eam_pot.atomBrickSel = dalloc<unsigned long long>((size_t)sim->boxes.nLocalBoxes, false);
+         HIP_CHECK(hipMemsetAsync(sim->eam_pot.atomBrickSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(unsigned long long), st));
+      }
+      if (STEP == 1) sim->eam_pot.atomRowsValid = 1;
+      if (STEP == 1 || sim->eam_pot.atomRowsValid) { b.rowsG = sim->eam_pot.atomRows; b.rowCountG = sim->eam_pot.atomRowCount; b.brickSel = sim->eam_pot.atomBrickSel; }
+   }
    if (cells_list) {      // a launch over a cell list: mark the cells, every brick looks at its own (zeroed on the launch stream, see launchEamBrick)
       if (!sim->eam_pot.cellSel) {
          sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
@@ -1236,6 +1249,7 @@ static void launchEamPair(SimGpu* sim, int num_cells, int* cells_list, int metho
       launchEamAtomBrick<STEP>(sim, a, num_cells, cells_list, st, spline);
       return;
    }
+   if (STEP == 1) sim->eam_pot.atomRowsValid = 0;      // (another method's pass 1: the rows EAM_Force_atom_brick left are not this evaluation's)
    if (eamListedBrick(sim, method)) {
       if (sim->atoms.neighborList.nBuilds == 0) { fprintf(stderr, "the *_nl methods need buildNeighborListGpu before the first force call\n"); exit(-1); }
       launchEamBrick<STEP>(sim, a, num_cells, cells_list, st, spline, true, method);
@@ -1334,7 +1348,7 @@ extern "C" void eamForce2GpuAsync(SimGpu* sim, int num_cells, int* cells_list, i
 {
    (void)spline;                            /* F(rhobar) is quadratic in both modes (gpu_utility.c:443) */
    if (num_cells <= 0) return;
-   if (sim->fuseEmbed && (method == CTA_CELL || eamListedBrick(sim, method))) return;      /* eamForce1Gpu[Async] has done it for these cells (SimGpu.fuseEmbed) */
+   if (sim->fuseEmbed && (method == CTA_CELL || eamListedBrick(sim, method) || eamAtomBrickPath(sim, method))) return;      /* eamForce1Gpu[Async] has done it for these cells (SimGpu.fuseEmbed) */
    EamArgs a = makeEamArgs(sim, num_cells, cells_list);
    // cta_cell in the overlap mode: pass 1 took whole bricks (launchEamBrick), the embedding follows the same groups over all local cells
    const int group = sim->eam_pot.brickGroup ? eamBrickGroupOf(sim, cells_list, num_cells, method) : 0;

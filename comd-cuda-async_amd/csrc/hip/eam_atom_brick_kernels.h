@@ -9,8 +9,11 @@
 //     (an LDS broadcast) -- and append the numbers of the records inside the cutoff to a row of its own in the LDS (16-bit numbers, 132-byte stride: the rows of
 //     a wave's lanes start on distinct banks).  EVALUATE: walk that row, two pairs per trip, branch-free inside the trip.  The divergence that is left is the
 //     row LENGTH (42 +- a few at 80^3), not the acceptance rate;
-//   * nothing is handed from pass 1 to pass 3: pass 3 tests again (the rows of 2 M atoms would cost a 260 MB round trip through HBM for 40 % of one pass), so
-//     a launch over any cell list is complete in itself and the two passes need not agree on anything.
+//   * pass 1 leaves the rows in memory, [brick][chunk of 8 numbers][atom of the brick] 16-byte elements (a wave's stores are dense KBs; the atom's index counts
+//     through ALL cells of the brick, selected or not, so launches over different cell lists never write the same element), and the selection it staged the
+//     brick under beside every cell.  Pass 3 asks for an atom's row while the block is being staged and skips the TEST phase when the cell was staged under the
+//     same selection (the numbers index the image, whose composition depends on the selection) -- otherwise it tests again: a launch over any cell list is
+//     complete in itself, the hand-over is an optimisation the two passes need not agree on.
 // A brick whose block outgrows the image takes the streaming form (eamCellDirect, a wave per cell) -- counted in stats[1], the host re-sizes the image.
 #pragma once
 #include "eam_brick_kernels.h"
@@ -24,7 +27,7 @@ __host__ __device__ static inline int eamAtomBrickRowStride(int rows) { return r
 // other waves of the 256 only help to stage: rows for threads that never have an atom would cost the second workgroup of a CU.)
 static inline size_t eamAtomBrickLdsBytes(int step, size_t tableDoubles, int imageCap, int rows, int rowThreads)
 {
-   return eamTableBytesAligned(tableDoubles) + eamBrickSharedBytes(step, imageCap) + 68 * sizeof(int)
+   return eamTableBytesAligned(tableDoubles) + eamBrickSharedBytes(step, imageCap) + (68 + 64) * sizeof(int)
           + (size_t)rowThreads * eamAtomBrickRowStride(rows) * sizeof(unsigned short);
 }
 
@@ -50,8 +53,9 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    int* sMisc = sBox + EAM_BRICK_MAX_CELLS;                  // [16]: 0/1 selection mask, 4 records in the image
    unsigned char* sList = (unsigned char*)(sMisc + 16);      // [64] selected cells of the brick, compacted
    int* sOwn = (int*)(sList + 64);                           // [65] atoms of the selected cells before cell k of that list
+   int* sFull = sOwn + 68;                                   // [64] atoms of the brick before brick cell c, selected or not (the hand-over's atom index)
    const int strideL = eamAtomBrickRowStride(b.rows);
-   unsigned short* __restrict__ myRow = (unsigned short*)(sOwn + 68) + (size_t)tid * strideL;
+   unsigned short* __restrict__ myRow = (unsigned short*)(sFull + 64) + (size_t)tid * strideL;
 
    // ---- the brick and its selected cells (as EAM_Force_cta_brick) ---------------------------------------------------------------------------
    const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2];
@@ -83,6 +87,9 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
       if (s) sList[__builtin_amdgcn_mbcnt_hi((unsigned)(selMask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)selMask, 0u))] = (unsigned char)lane;
    }
 
+   int brickCnt = 0;                                         // wave 0, lane c: atoms of brick cell c (local cells: their occupancies stand during a force evaluation)
+   if (b.rowsG && wave == 0 && lane < NC && by0 + lane % b.by < gy && bz0 + lane / b.by < gz) brickCnt = a.nAtoms[comdBoxFromTuple(&b.geom, bx, by0 + lane % b.by, bz0 + lane / b.by)];
+
    // ---- ONE round trip for the block: occupancies and records are requested together (slot s of block cell h = task SLOTS h + s) ---------------
    real_t lx[STAGE], ly[STAGE], lz[STAGE], ld[STAGE];
    bool lok[STAGE];
@@ -98,34 +105,53 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          if (STEP == 3) ld[k] = *reinterpret_cast<const real_t*>(reinterpret_cast<const char*>(a.dfEmbed) + o);
       }
    };
-   // every wave works out the cell ids of all 128 block cells (two per lane; -1: outside the grid or in no selected cell's stencil -- a launch over the
-   // interior cells runs while the halo cells are being filled and must not look at them)
-   auto blockBox = [&](const int h) {
-      int box = -1;
-      if (h < NH) {
-         const int xh = h % 3, yh = (h / 3) % HY, zh = h / (3 * HY);
-         const int iy = by0 + yh - 1, iz = bz0 + zh - 1;
-         if (iy <= gy && iz <= gz) {
-            bool need = false;
+   // A brick away from the faces of the local grid with every cell selected -- nearly all of them -- has a block of local cells, numbered
+   // x + gx (y + gy z), all of them needed.
+   const bool plain = !b.geom.lookup && selMask == (NC >= 64 ? ~0ull : (1ull << NC) - 1ull) && bx >= 1 && bx <= gx - 2 && by0 >= 1 && by0 + b.by <= gy - 1
+                      && bz0 >= 1 && bz0 + b.bz <= gz - 1;
+   if (plain) {
+      const int hyMagic = (65536 + HY - 1) / HY;             // t / HY = (t * hyMagic) >> 16 for t < 128
+      const int base = (bx - 1) + gx * ((by0 - 1) + gy * (bz0 - 1)), gxy = gx * gy;
+      auto plainBox = [&](const int h) {                     // h = xh + 3 (yh + HY zh)
+         const int t = (h * 171) >> 9, xh = h - 3 * t, zh = (t * hyMagic) >> 16, yh = t - zh * HY;
+         return base + xh + gx * yh + gxy * zh;
+      };
+      if (tid < NH) myBox = plainBox(tid);
 #pragma unroll
-            for (int dz = -1; dz <= 1; ++dz)
-#pragma unroll
-               for (int dy = -1; dy <= 1; ++dy) {
-                  const int cy = yh - 1 + dy, cz = zh - 1 + dz;
-                  if (cy >= 0 && cy < b.by && cz >= 0 && cz < b.bz) need = need || ((selMask >> (cy + b.by * cz)) & 1ull);
-               }
-            if (need) box = comdBoxFromTuple(&b.geom, bx + xh - 1, iy, iz);
-         }
+      for (int k = 0; k < STAGE; ++k) {
+         const int task = k * nThreads + tid, h = task >> SLOT_BITS;
+         request(k, h < NH ? plainBox(h) : -1, task & (SLOTS - 1));
       }
-      return box;
-   };
-   const int boxLo = blockBox(lane), boxHi = blockBox(64 + lane);
-   if (wave < 2) myBox = wave == 0 ? boxLo : boxHi;
+   } else {
+      // every wave works out the cell ids of all 128 block cells (two per lane; -1: outside the grid or in no selected cell's stencil -- a launch over the
+      // interior cells runs while the halo cells are being filled and must not look at them)
+      auto blockBox = [&](const int h) {
+         int box = -1;
+         if (h < NH) {
+            const int xh = h % 3, yh = (h / 3) % HY, zh = h / (3 * HY);
+            const int iy = by0 + yh - 1, iz = bz0 + zh - 1;
+            if (iy <= gy && iz <= gz) {
+               bool need = false;
 #pragma unroll
-   for (int k = 0; k < STAGE; ++k) {
-      const int task = k * nThreads + tid, h = task >> SLOT_BITS;
-      const int fromLo = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxLo), fromHi = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxHi);
-      request(k, h < NH ? (h < 64 ? fromLo : fromHi) : -1, task & (SLOTS - 1));
+               for (int dz = -1; dz <= 1; ++dz)
+#pragma unroll
+                  for (int dy = -1; dy <= 1; ++dy) {
+                     const int cy = yh - 1 + dy, cz = zh - 1 + dz;
+                     if (cy >= 0 && cy < b.by && cz >= 0 && cz < b.bz) need = need || ((selMask >> (cy + b.by * cz)) & 1ull);
+                  }
+               if (need) box = comdBoxFromTuple(&b.geom, bx + xh - 1, iy, iz);
+            }
+         }
+         return box;
+      };
+      const int boxLo = blockBox(lane), boxHi = blockBox(64 + lane);
+      if (wave < 2) myBox = wave == 0 ? boxLo : boxHi;
+#pragma unroll
+      for (int k = 0; k < STAGE; ++k) {
+         const int task = k * nThreads + tid, h = task >> SLOT_BITS;
+         const int fromLo = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxLo), fromHi = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxHi);
+         request(k, h < NH ? (h < 64 ? fromLo : fromHi) : -1, task & (SLOTS - 1));
+      }
    }
    int myCnt = 0;
    if (myBox >= 0) myCnt = a.nAtoms[myBox];
@@ -160,6 +186,10 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
       for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inclOwn, d); if (lane >= d) inclOwn += up; }
       sOwn[lane + 1] = inclOwn;
       if (lane == 0) sOwn[0] = 0;
+      int inclFull = brickCnt;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inclFull, d); if (lane >= d) inclFull += up; }
+      sFull[lane] = inclFull - brickCnt;
    }
    __syncthreads();
    const int imageTotal = uniform(sMisc[4]);
@@ -168,9 +198,40 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
       if (STEP == 1 && b.stats && tid == 0) atomicAdd(&b.stats[1], 1);
       for (int pick = wave; pick < nSel; pick += nWaves) {
          const int cl = sList[pick], hc = 1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1));
+         if (STEP == 1 && b.brickSel && lane == 0) b.brickSel[sBox[hc]] = 0ull;      // no rows for this cell
          eamCellDirect<STEP, SPLINE>(a, uniform(sBox[hc]), lane, rhoT, phiT, sameGrid, b.fuseEmbed);
       }
       return;
+   }
+   // own atom t of the brick -> its cell (k-th selected, brick cell cl) and its number in the cell
+   const int nOwn = uniform(sOwn[nSel]);
+   const int rowThreads = b.listRounds;                      // threads that take atoms (whole waves)
+   auto ownAtom = [&](const int t, int& cl, int& ia) {
+      int k = 0;
+      for (int s = 1; s < nSel; ++s) k += t >= sOwn[s] ? 1 : 0;
+      cl = sList[k]; ia = t - sOwn[k];
+   };
+   // the selection is written beside the cells whose rows this launch leaves (pass 1); pass 3 asks for the first round's rows now, a staging away from their use
+   constexpr int CH = 6;                                     // chunks of 8 numbers asked for ahead (48 neighbours; the FCC count inside 4.95 A is 42)
+   uint4 pre[CH];
+   unsigned preN = 0xffffu;
+   unsigned long long preSel = ~selMask;
+   const uint4* __restrict__ rowsG4 = reinterpret_cast<const uint4*>(b.rowsG) + (size_t)bid * (b.rows >> 3) * 256;      // [brick][rows / 8 chunks][256 atoms]
+#pragma unroll
+   for (int c = 0; c < CH; ++c) pre[c] = make_uint4(0u, 0u, 0u, 0u);
+   if (STEP == 3 && b.rowsG && (wave << 6) < rowThreads && (wave << 6) < nOwn) {
+      int cl, ia; ownAtom((wave << 6) + lane < nOwn ? (wave << 6) + lane : nOwn - 1, cl, ia);
+      const int full = sFull[cl] + ia;
+      if (full < 256) {
+         preN = b.rowCountG[(size_t)bid * 256 + full];
+         preSel = b.brickSel[sBox[1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1))]];
+#pragma unroll
+         for (int c = 0; c < CH; ++c) pre[c] = rowsG4[c * 256 + full];
+      }
+   }
+   if (STEP == 1 && b.rowsG && wave == 0 && lane < nSel) {
+      const int cl = sList[lane];
+      b.brickSel[sBox[1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1))]] = selMask;
    }
 #pragma unroll
    for (int k = 0; k < STAGE; ++k) {
@@ -198,16 +259,26 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
 
    if (b.debug & 4) return;
    // ---- thread t takes own atom t, t + 256, ... ----------------------------------------------------------------------------------------------------
-   const int nOwn = uniform(sOwn[nSel]);
-   const int rowThreads = b.listRounds;                      // threads that take atoms (whole waves)
    if ((wave << 6) >= rowThreads) return;
    for (int base = wave << 6; base < nOwn; base += rowThreads) {      // (wave-uniform: a wave whose 64 atoms do not exist has nothing to do)
       const bool have = base + lane < nOwn;
       const int t = have ? base + lane : nOwn - 1;           // lanes past the last atom repeat it and store nothing: the walk below has wave-uniform parts
-      int k = 0;
-      for (int s = 1; s < nSel; ++s) k += t >= sOwn[s] ? 1 : 0;
-      const int cl = sList[k], yh = cl % b.by + 1, zh = cl / b.by + 1, hc = 1 + 3 * (yh + HY * zh);
-      const int iBox = sBox[hc], ia = t - sOwn[k], recI = sOff[hc] + ia;
+      int cl, ia; ownAtom(t, cl, ia);
+      const int yh = cl % b.by + 1, zh = cl / b.by + 1, hc = 1 + 3 * (yh + HY * zh);
+      const int iBox = sBox[hc], recI = sOff[hc] + ia;
+      const bool firstRound = base == (wave << 6);
+      // pass 3: the rows of pass 1, when every atom of the wave has one that was numbered against this image
+      bool handed = false;
+      if (STEP == 3 && firstRound && __builtin_amdgcn_ballot_w64(preN != 0xffffu && preSel == selMask) == ~0ull) {
+         handed = true;
+         unsigned* __restrict__ rowW = reinterpret_cast<unsigned*>(myRow);
+#pragma unroll
+         for (int c = 0; c < CH; ++c) { rowW[4 * c] = pre[c].x; rowW[4 * c + 1] = pre[c].y; rowW[4 * c + 2] = pre[c].z; rowW[4 * c + 3] = pre[c].w; }
+         for (int c = CH; c < (int)(preN + 7u) >> 3; ++c) {      // a row beyond 48 numbers: blocking
+            const uint4 v = rowsG4[c * 256 + sFull[cl] + ia];
+            rowW[4 * c] = v.x; rowW[4 * c + 1] = v.y; rowW[4 * c + 2] = v.z; rowW[4 * c + 3] = v.w;
+         }
+      }
       const real_t xi = sp[REC * recI], yi = sp[REC * recI + 1], zi = sp[REC * recI + 2];
       const real_t dfi = (STEP == 3) ? sd[recI] : R(0.0);
 
@@ -221,7 +292,7 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
       bool over = false;                                    // more hits than the row holds
       constexpr int G = 4;
 #pragma unroll 1
-      for (int p = (b.debug & 1) ? 3 : 0; p < 3; ++p) {
+      for (int p = ((b.debug & 1) || handed) ? 3 : 0; p < 3; ++p) {
          const int rs = sOff[3 * ((yh - 1) + HY * (zh - 1 + p))], len = sOff[3 * ((yh + 1) + HY * (zh - 1 + p)) + 3] - rs;
          real_t ax[G], ay[G], az[G], cx[G], cy[G], cz[G];
          int whole = len / (2 * G);
@@ -281,7 +352,16 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          };
          for (; u < len; u += G) { ask(u, ax, ay, az); test(u, ax, ay, az); }
       }
-      int n = over ? b.rows + 1 : (int)(w - myRow);
+      int n = handed ? (int)preN : over ? b.rows + 1 : (int)(w - myRow);
+      if (STEP == 1 && b.rowsG && firstRound && have) {      // leave the row for pass 3 (a row that outgrew its capacity: marked, pass 3 tests again)
+         const int full = sFull[cl] + ia;
+         if (full < 256) {
+            b.rowCountG[(size_t)bid * 256 + full] = (unsigned short)(n > b.rows ? 0xffff : n);
+            uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + (size_t)bid * (b.rows >> 3) * 256 + full;
+            const unsigned* __restrict__ rowR = reinterpret_cast<const unsigned*>(myRow);
+            for (int c = 0; c < (n > b.rows ? 0 : (n + 7) >> 3); ++c) dst[c * 256] = make_uint4(rowR[4 * c], rowR[4 * c + 1], rowR[4 * c + 2], rowR[4 * c + 3]);
+         }
+      }
       // EVALUATE: two pairs per trip, branch-free; a missing second pair is evaluated at r = cutoff and weighted 0
       real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0);
       auto evalTrip = [&](const int j0, const int j1, const bool h1) {

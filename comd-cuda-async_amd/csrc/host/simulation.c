@@ -198,7 +198,7 @@ SimFlat* initSimulation(Command cmd)
    free(nbrTable);
    /* cta_cell: pass 1 applies the embedding function to the atoms it has just summed rhobar for; eamForce2Gpu then has nothing left to do.
     * Not in profiling mode (-s), which runs pass 1 alone and expects the reference's pass-1 state. */
-   sim->gpu.fuseEmbed = cmd.doeam && (sim->method == CTA_CELL || sim->method == THREAD_ATOM_NL) && !sim->gpuProfile;   /* (the list method: when the device library keeps brick rows, comd_hip.h NeighborListGpu.slabFormat 4) */
+   sim->gpu.fuseEmbed = cmd.doeam && (sim->method == CTA_CELL || sim->method == THREAD_ATOM_NL || sim->method == THREAD_ATOM || sim->method == WARP_ATOM) && !sim->gpuProfile;   /* (the list method: when the device library keeps brick rows, comd_hip.h NeighborListGpu.slabFormat 4) */
 
    sim->atomExchange = initAtomHaloExchange(sim->domain, sim->boxes, 1);
    if (cmd.doeam) ((EamPotential*)sim->pot)->forceExchange = initForceHaloExchange(sim->domain, sim->boxes, 1);

@@ -110,6 +110,10 @@ typedef struct EamPotentialGpuSt {
    /* [round 4] method thread_atom (EAM_Force_atom_brick, hip/eam_atom_brick_kernels.h): thread per atom inside a brick workgroup; a shape and an image of its own */
    int     atomBrickBy, atomBrickBz;   /* host: brick shape (0: chosen by the first launch) */
    int     atomBrickImageCap;          /* host: records of its LDS image (0: sized by the next launch) */
+   unsigned* atomRows;                 /* device [bricks][rows / 8][256] uint4: the rows pass 1 leaves for pass 3, 8 image numbers per element, atom = its index in the brick */
+   unsigned short* atomRowCount;       /* device [bricks][256]: their lengths (0xffff: no row) */
+   unsigned long long* atomBrickSel;   /* device [nLocalBoxes]: the selection of its brick a cell's rows were numbered under (0: none) */
+   int     atomRowsValid;              /* host: the last pass 1 of this simulation was EAM_Force_atom_brick's (else pass 3 tests again) */
 } EamPotentialGpu;
 
 /* gpu_types.h:98-112 */

@@ -3,4 +3,5 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
 python3 -m pytest $R/tests -m gpu -x -q -k "thread_atom and (eam or any_cell or sweep or recorded)" > $R/gpurun_out/r04_atom_tests.log 2>&1 || { tail -30 $R/gpurun_out/r04_atom_tests.log; exit 1; }
 tail -2 $R/gpurun_out/r04_atom_tests.log
-bash $R/profiles/r04_sweep.sh "--pot eam --method thread_atom --steps 20 --warmup 5" COMD_EAM_ABLATE 0 2 1
+bash $R/profiles/r04_sweep.sh "--pot eam --method thread_atom --steps 20 --warmup 5" COMD_EAM_ATOM_HANDOVER 1 0
+bash $R/profiles/r04_sweep.sh "--pot eam --method thread_atom --steps 20 --warmup 5 --overlap" COMD_EAM_ATOM_HANDOVER 1 0

@@ -165,6 +165,42 @@ def test_eam_overlap_mode_takes_whole_bricks(gpu, orc, monkeypatch, env):
         assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < TOL["eam_dfembed_abs"]
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
+@pytest.mark.parametrize("env", [{}, {"COMD_EAM_ATOM_HANDOVER": "0"}, {"COMD_EAM_IMAGE": "128"}, {"COMD_EAM_IMAGE": "1500"}, {"COMD_EAM_ATOM_BRICK": "2,3"},
+                                 {"COMD_EAM_ATOM_BRICK": "4,5"}, {"COMD_EAM_ATOM_ROWS": "16"}, {"COMD_EAM_ATOM_ROWS": "48"}, {"COMD_EAM_THREAD_ATOM": "cell"}])
+def test_eam_thread_atom_on_the_brick_image(gpu, orc, monkeypatch, env, overlap):
+    """-m thread_atom -e: a thread per atom inside a brick workgroup (eam_atom_brick_kernels.h).  Legs: the default; pass 3 testing again instead of reading
+    the rows of pass 1; an image every brick (128 records) or part of the bricks (1500) outgrow -- those take the streaming form, in both passes; brick shapes
+    that do not divide the grid / fill all four waves; rows shorter than the neighbour count of every atom (16: each walks its stencil a second time) or of
+    some atoms (48); round 2's kernel.  Each without and with -a 1 (every pass once over the boundary and once over the interior cells: bricks that hold
+    cells of both lists are staged under two selections, the hand-over must notice).  Forces, energies, densities, dF/drho against the oracle."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    with gpu.Simulation(_args((14, 12, 13), 1, 0.2, "thread_atom", extra=("-a", overlap))) as sim:
+        o = orc.Oracle((14, 12, 13), eam=1, delta=0.2, cap=max(sim.max_atoms, 64))
+        sim.step(3)
+        o.step(3)
+        fo = o.gather(orc.F)
+        assert np.abs(sim.gather(2) - fo).max() <= TOL["force_rel_to_max"] * np.abs(fo).max()
+        assert np.abs(sim.gather(3) - o.gather(orc.U)).max() <= TOL["per_atom_energy_abs"]
+        assert np.abs(sim.gather(4) - o.gather(orc.RHOBAR)).max() < TOL["eam_density_abs"]
+        assert np.abs(sim.gather(5) - o.gather(orc.DFEMBED)).max() < TOL["eam_dfembed_abs"]
+
+
+def test_eam_thread_atom_hand_over_changes_no_bit(gpu, monkeypatch):
+    """The rows pass 1 leaves for pass 3 hold what pass 3's own test would find, in the same order: forces and energies with and without the hand-over are the
+    same to the last bit -- on one launch per pass and with -a 1 (bricks staged under two selections; the two modes order the atoms of a cell differently and
+    are not compared with each other)."""
+    got = []
+    for handover, overlap in (("1", 0), ("0", 0), ("1", 1), ("0", 1)):
+        monkeypatch.setenv("COMD_EAM_ATOM_HANDOVER", handover)
+        with gpu.Simulation(_args((12, 14, 11), 1, 0.15, "thread_atom", extra=("-a", overlap))) as sim:
+            sim.step(4)
+            got.append((sim.gather(2).copy(), sim.gather(3).copy()))
+    for k in (0, 2):
+        assert np.array_equal(got[k][0], got[k + 1][0]) and np.array_equal(got[k][1], got[k + 1][1])
+
+
 def test_eam_pass_3_over_another_partition_than_pass_1_stops_the_run():
     """The contract of the cta_cell passes (include/comd_hip.h): eamForce3Gpu[Async] must cover the cells with the partition of the eamForce1Gpu[Async] calls of
     the same force evaluation -- the 16-bit numbers pass 1 leaves index the LDS image of a brick, and the image holds the stencils of the SELECTED cells only.
