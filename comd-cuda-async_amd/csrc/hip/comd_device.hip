@@ -814,11 +814,19 @@ static bool eamBrickPath(const SimGpu* sim, int method)
           && (double)sim->boxes.nTotalBoxes * sim->maxAtoms * sizeof(real_t) < 4294967296.0;      // (the brick kernel stages with 32-bit byte offsets)
 }
 
+// thread_atom on the brick image (eam_atom_brick_kernels.h).  COMD_EAM_THREAD_ATOM=cell keeps round 2's kernel (a share of a wave per cell, candidates streamed
+// through L2; A/B runs), as do arrays of 4 GiB or more (the staging uses 32-bit byte offsets).
+static bool eamAtomBrickPath(const SimGpu* sim, int method)
+{
+   return (method == THREAD_ATOM || method == WARP_ATOM) && !(getenv("COMD_EAM_THREAD_ATOM") && !strcmp(getenv("COMD_EAM_THREAD_ATOM"), "cell"))
+          && (double)sim->boxes.nTotalBoxes * sim->maxAtoms * sizeof(real_t) < 4294967296.0;
+}
+
 // The overlap mode's two lists as brick groups (eam_brick_kernels.h ClassifyBrickCells): 1 = this is the launch over SimGpu.boundary_cells, 2 = over
 // SimGpu.interior_cells, 0 = any other list (cell marks).  COMD_EAM_GROUPS=0 keeps the lists as they are given (A/B runs, tests).
 static int eamBrickGroupOf(const SimGpu* sim, const int* cells_list, int num_cells, int method)
 {
-   if (!cells_list || !eamBrickPath(sim, method)) return 0;
+   if (!cells_list || !(eamBrickPath(sim, method) || eamAtomBrickPath(sim, method))) return 0;
    if (getenv("COMD_EAM_GROUPS") && atoi(getenv("COMD_EAM_GROUPS")) == 0) return 0;
    if (cells_list == sim->boundary_cells && num_cells == sim->n_boundary_cells) return 1;
    if (cells_list == sim->interior_cells && num_cells == sim->n_interior_cells) return 2;
@@ -985,6 +993,37 @@ static void eamBrickBuildLists(SimGpu* sim, hipStream_t st, int spline)
    sim->eam_pot.brickListMakes++;
 }
 
+// The bricks of the boundary and of the interior launch as lists, for the brick shape in `b` (built once per shape; eam_pot.brickGroup marks the cells for
+// kernels over cells).  Shared by cta_cell and thread_atom on the brick image.
+static void eamBrickGroupLists(SimGpu* sim, const EamBrickArgs& b, hipStream_t st)
+{
+   if (sim->eam_pot.brickGroup && sim->eam_pot.brickGroupBy == b.by && sim->eam_pot.brickGroupBz == b.bz) return;
+   if (!sim->eam_pot.brickGroup) sim->eam_pot.brickGroup = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
+   if (!sim->eam_pot.cellSel) {
+      sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
+      HIP_CHECK(hipMemsetAsync(sim->eam_pot.cellSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(int), st));
+   }
+   const int tag = ++sim->eam_pot.selTag;
+   const EamBrickArgs g = b;
+   if (sim->n_boundary_cells > 0)
+      hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(sim->n_boundary_cells, 256)), dim3(256), 0, st, sim->boundary_cells, sim->n_boundary_cells, sim->eam_pot.cellSel, tag);
+   const int nBricks = b.geom.g[0] * b.nby * b.nbz;
+   if (sim->eam_pot.brickList) HIP_CHECK(hipFree(sim->eam_pot.brickList));
+   sim->eam_pot.brickList = dalloc<int>((size_t)2 * nBricks, false);
+   hipLaunchKernelGGL(ClassifyBrickCells, dim3(ceilDiv(nBricks, 256)), dim3(256), 0, st, g, sim->eam_pot.cellSel, tag, sim->eam_pot.brickGroup, sim->eam_pot.brickList);
+   // the bricks of either group as a list (built once; the other stream of the overlap mode reads groups and lists too, so wait here):
+   // [0, n1) the bricks that hold a boundary cell, [nBricks, nBricks + n2) the others, each in brick order
+   std::vector<int> cls((size_t)nBricks), lists((size_t)2 * nBricks, 0);
+   HIP_CHECK(hipMemcpyAsync(cls.data(), sim->eam_pot.brickList, (size_t)nBricks * sizeof(int), hipMemcpyDeviceToHost, st));
+   HIP_CHECK(hipStreamSynchronize(st));
+   int n1 = 0, n2 = 0;
+   for (int i = 0; i < nBricks; ++i) { if (cls[i] == 1) lists[n1++] = i; else lists[(size_t)nBricks + n2++] = i; }
+   HIP_CHECK(hipMemcpyAsync(sim->eam_pot.brickList, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice, st));
+   HIP_CHECK(hipStreamSynchronize(st));
+   sim->eam_pot.brickCount[0] = n1; sim->eam_pot.brickCount[1] = n2; sim->eam_pot.brickListStride = nBricks;
+   sim->eam_pot.brickGroupBy = b.by; sim->eam_pot.brickGroupBz = b.bz;
+}
+
 template <int STEP>
 static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* cells_list, hipStream_t st, int spline, bool listed, int method)
 {
@@ -1036,32 +1075,7 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
       b.brickList = sim->eam_pot.brickList + (size_t)(group ? group - 1 : 2) * sim->eam_pot.brickListStride;
    }
    if (group && !listed) {            // the boundary / interior launch of the overlap mode: whole bricks (a brick with cells of both lists would be staged twice per pass)
-      if (!sim->eam_pot.brickGroup || sim->eam_pot.brickGroupBy != b.by || sim->eam_pot.brickGroupBz != b.bz) {
-         if (!sim->eam_pot.brickGroup) sim->eam_pot.brickGroup = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
-         if (!sim->eam_pot.cellSel) {
-            sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
-            HIP_CHECK(hipMemsetAsync(sim->eam_pot.cellSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(int), st));
-         }
-         const int tag = ++sim->eam_pot.selTag;
-         const EamBrickArgs g = b;
-         if (sim->n_boundary_cells > 0)
-            hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(sim->n_boundary_cells, 256)), dim3(256), 0, st, sim->boundary_cells, sim->n_boundary_cells, sim->eam_pot.cellSel, tag);
-         const int nBricks = b.geom.g[0] * b.nby * b.nbz;
-         if (sim->eam_pot.brickList) HIP_CHECK(hipFree(sim->eam_pot.brickList));
-         sim->eam_pot.brickList = dalloc<int>((size_t)2 * nBricks, false);
-         hipLaunchKernelGGL(ClassifyBrickCells, dim3(ceilDiv(nBricks, 256)), dim3(256), 0, st, g, sim->eam_pot.cellSel, tag, sim->eam_pot.brickGroup, sim->eam_pot.brickList);
-         // the bricks of either group as a list (built once; the other stream of the overlap mode reads groups and lists too, so wait here):
-         // [0, n1) the bricks that hold a boundary cell, [nBricks, nBricks + n2) the others, each in brick order
-         std::vector<int> cls((size_t)nBricks), lists((size_t)2 * nBricks, 0);
-         HIP_CHECK(hipMemcpyAsync(cls.data(), sim->eam_pot.brickList, (size_t)nBricks * sizeof(int), hipMemcpyDeviceToHost, st));
-         HIP_CHECK(hipStreamSynchronize(st));
-         int n1 = 0, n2 = 0;
-         for (int i = 0; i < nBricks; ++i) { if (cls[i] == 1) lists[n1++] = i; else lists[(size_t)nBricks + n2++] = i; }
-         HIP_CHECK(hipMemcpyAsync(sim->eam_pot.brickList, lists.data(), lists.size() * sizeof(int), hipMemcpyHostToDevice, st));
-         HIP_CHECK(hipStreamSynchronize(st));
-         sim->eam_pot.brickCount[0] = n1; sim->eam_pot.brickCount[1] = n2; sim->eam_pot.brickListStride = nBricks;
-         sim->eam_pot.brickGroupBy = b.by; sim->eam_pot.brickGroupBz = b.bz;
-      }
+      eamBrickGroupLists(sim, b, st);
       // every cell of a listed brick is selected: no marks to look at (the embedding pass, a kernel over cells, uses brickGroup)
       b.brickList = sim->eam_pot.brickList + (group == 1 ? 0 : sim->eam_pot.brickListStride);
    } else if (cells_list && !group) {      // a launch over any other cell list: mark the cells, every brick looks at its own
@@ -1103,14 +1117,6 @@ static void launchEamBrick(SimGpu* sim, const EamArgs& a, int num_cells, int* ce
 #undef COMD_LAUNCH_EAM_BRICK_C
 #undef COMD_LAUNCH_EAM_BRICK
    LAUNCH_CHECK();
-}
-
-// thread_atom on the brick image (eam_atom_brick_kernels.h).  COMD_EAM_THREAD_ATOM=cell keeps round 2's kernel (a share of a wave per cell, candidates streamed
-// through L2; A/B runs), as do arrays of 4 GiB or more (the staging uses 32-bit byte offsets).
-static bool eamAtomBrickPath(const SimGpu* sim, int method)
-{
-   return (method == THREAD_ATOM || method == WARP_ATOM) && !(getenv("COMD_EAM_THREAD_ATOM") && !strcmp(getenv("COMD_EAM_THREAD_ATOM"), "cell"))
-          && (double)sim->boxes.nTotalBoxes * sim->maxAtoms * sizeof(real_t) < 4294967296.0;
 }
 
 template <int STEP>
@@ -1178,7 +1184,11 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
       if (STEP == 1) sim->eam_pot.atomRowsValid = 1;
       if (STEP == 1 || sim->eam_pot.atomRowsValid) { b.rowsG = sim->eam_pot.atomRows; b.rowCountG = sim->eam_pot.atomRowCount; b.brickSel = sim->eam_pot.atomBrickSel; }
    }
-   if (cells_list) {      // a launch over a cell list: mark the cells, every brick looks at its own (zeroed on the launch stream, see launchEamBrick)
+   const int group = eamBrickGroupOf(sim, cells_list, num_cells, THREAD_ATOM);
+   if (group) {      // the boundary / interior launch of the overlap mode: whole bricks, as cta_cell (a brick with cells of both lists would be staged twice per pass)
+      eamBrickGroupLists(sim, b, st);
+      b.brickList = sim->eam_pot.brickList + (group == 1 ? 0 : sim->eam_pot.brickListStride);
+   } else if (cells_list) {      // a launch over any other cell list: mark the cells, every brick looks at its own (zeroed on the launch stream, see launchEamBrick)
       if (!sim->eam_pot.cellSel) {
          sim->eam_pot.cellSel = dalloc<int>((size_t)sim->boxes.nLocalBoxes, false);
          HIP_CHECK(hipMemsetAsync(sim->eam_pot.cellSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(int), st));
@@ -1189,7 +1199,7 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    }
    const size_t lds = eamAtomBrickLdsBytes(STEP, tableDoublesOf(STEP), b.imageCap, b.rows, b.listRounds);
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: thread_atom needs %zu bytes of LDS for this box\n", lds); exit(-1); }
-   const int grid = b.geom.g[0] * b.nby * b.nbz;
+   const int grid = group ? sim->eam_pot.brickCount[group - 1] : b.geom.g[0] * b.nby * b.nbz;
    if (grid <= 0) return;
    const double rcut = sim->eam_pot.cutoff * (1.0 + 4e-16);      // (as launchEamBrick: the table clamps are dead weight when every evaluated pair lies inside the tables)
    const bool clampFree = !spline && a.phi.x0 <= R(0.0) && a.rho.x0 <= R(0.0) && rcut <= (double)a.phi.xn && rcut <= (double)a.rho.xn

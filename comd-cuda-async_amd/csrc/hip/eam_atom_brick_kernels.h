@@ -59,7 +59,7 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
 
    // ---- the brick and its selected cells (as EAM_Force_cta_brick) ---------------------------------------------------------------------------
    const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2];
-   const int bid = xcdRemap(blockIdx.x, gridDim.x);          // x fastest: consecutive bricks share two thirds of their block
+   const int bid = b.brickList ? b.brickList[xcdRemap(blockIdx.x, gridDim.x)] : xcdRemap(blockIdx.x, gridDim.x);      // x fastest: consecutive bricks share two thirds of their block
    const int bx = bid % gx, by0 = ((bid / gx) % b.nby) * b.by, bz0 = (bid / (gx * b.nby)) * b.bz;
    const int HY = b.by + 2, HZ = b.bz + 2, NH = 3 * HY * HZ, NC = b.by * b.bz;
    unsigned long long selMask;

@@ -167,13 +167,14 @@ def test_eam_overlap_mode_takes_whole_bricks(gpu, orc, monkeypatch, env):
 
 @pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("env", [{}, {"COMD_EAM_ATOM_HANDOVER": "0"}, {"COMD_EAM_IMAGE": "128"}, {"COMD_EAM_IMAGE": "1500"}, {"COMD_EAM_ATOM_BRICK": "2,3"},
-                                 {"COMD_EAM_ATOM_BRICK": "4,5"}, {"COMD_EAM_ATOM_ROWS": "16"}, {"COMD_EAM_ATOM_ROWS": "48"}, {"COMD_EAM_THREAD_ATOM": "cell"}])
+                                 {"COMD_EAM_ATOM_BRICK": "4,5"}, {"COMD_EAM_ATOM_ROWS": "16"}, {"COMD_EAM_ATOM_ROWS": "48"}, {"COMD_EAM_THREAD_ATOM": "cell"}, {"COMD_EAM_GROUPS": "0"}])
 def test_eam_thread_atom_on_the_brick_image(gpu, orc, monkeypatch, env, overlap):
     """-m thread_atom -e: a thread per atom inside a brick workgroup (eam_atom_brick_kernels.h).  Legs: the default; pass 3 testing again instead of reading
     the rows of pass 1; an image every brick (128 records) or part of the bricks (1500) outgrow -- those take the streaming form, in both passes; brick shapes
     that do not divide the grid / fill all four waves; rows shorter than the neighbour count of every atom (16: each walks its stencil a second time) or of
-    some atoms (48); round 2's kernel.  Each without and with -a 1 (every pass once over the boundary and once over the interior cells: bricks that hold
-    cells of both lists are staged under two selections, the hand-over must notice).  Forces, energies, densities, dF/drho against the oracle."""
+    some atoms (48); round 2's kernel; the lists of -a 1 taken cell by cell (COMD_EAM_GROUPS=0: bricks that hold cells of both lists are staged under two
+    selections, the hand-over must notice) instead of as whole bricks.  Each without and with -a 1 (every pass once over the boundary and once over the
+    interior cells).  Forces, energies, densities, dF/drho against the oracle."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     with gpu.Simulation(_args((14, 12, 13), 1, 0.2, "thread_atom", extra=("-a", overlap))) as sim:
@@ -192,6 +193,7 @@ def test_eam_thread_atom_hand_over_changes_no_bit(gpu, monkeypatch):
     same to the last bit -- on one launch per pass and with -a 1 (bricks staged under two selections; the two modes order the atoms of a cell differently and
     are not compared with each other)."""
     got = []
+    monkeypatch.setenv("COMD_EAM_GROUPS", "0")      # (-a 1 with the lists taken cell by cell: the case in which pass 3 finds cells staged under another selection)
     for handover, overlap in (("1", 0), ("0", 0), ("1", 1), ("0", 1)):
         monkeypatch.setenv("COMD_EAM_ATOM_HANDOVER", handover)
         with gpu.Simulation(_args((12, 14, 11), 1, 0.15, "thread_atom", extra=("-a", overlap))) as sim:
