@@ -45,6 +45,10 @@ COMD_HALO_MIRROR=0 python bench.py --pot eam --no-variants --no-cpu-baseline > $
 COMD_HALO_MIRROR=0 python bench.py --pot eam --method thread_atom_nl --no-variants --no-cpu-baseline > $O/plain_eam_nl_messages.json 2>/dev/null
 python bench.py --pot eam --method thread_atom_nl --no-variants --no-cpu-baseline > $O/plain_eam_nl.json 2>/dev/null
 COMD_EAM_NL=lds python bench.py --pot eam --method thread_atom_nl --no-variants --no-cpu-baseline > $O/plain_eam_nl_round3_kernel.json 2>/dev/null
+python bench.py --pot eam --method thread_atom --no-variants --no-cpu-baseline > $O/plain_eam_thread_atom.json 2>/dev/null
+COMD_EAM_THREAD_ATOM=cell python bench.py --pot eam --method thread_atom --no-variants --no-cpu-baseline > $O/plain_eam_thread_atom_round2_kernel.json 2>/dev/null
+COMD_EAM_ATOM_HANDOVER=0 python bench.py --pot eam --method thread_atom --no-variants --no-cpu-baseline > $O/plain_eam_thread_atom_no_handover.json 2>/dev/null
+COMD_LOOPBACK_TRANSPORT=1 python bench.py --pot eam --method thread_atom --async-halo 1 --no-variants --no-cpu-baseline > $O/loopback_eam_thread_atom_overlap.json 2>/dev/null
 COMD_LOOPBACK_TRANSPORT=1 python bench.py --pot eam --method thread_atom_nl --async-halo 1 --no-variants --no-cpu-baseline > $O/loopback_eam_nl_overlap.json 2>/dev/null
 echo "loopback benches done"
 exit 0
@@ -56,14 +60,14 @@ for c in "lj thread_atom" "lj thread_atom_nl" "lj cta_cell" "eam cta_cell" "eam 
   echo "stats $1 $2"
 done
 COMD_LOOPBACK_TRANSPORT=1 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_loopback_lj -o out -- python3 $R/bench.py --no-cpu-baseline --no-variants --steps 50 --warmup 5 > $O/stats_loopback_lj.log 2>&1
-for c in "lj thread_atom" "lj thread_atom_nl" "eam cta_cell" "eam thread_atom_nl"; do
+for c in "lj thread_atom" "lj thread_atom_nl" "eam cta_cell" "eam thread_atom_nl" "eam thread_atom"; do
   set -- $c
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_$1_$2_$ctr -o out -- python3 $R/bench.py --pot $1 --method $2 --no-cpu-baseline --no-variants --no-target-line --steps 10 --warmup 3 > $O/pmc_$1_$2_$ctr.log 2>&1
   done
   echo "pmc $1 $2"
 done
-for c in "lj thread_atom" "eam cta_cell" "eam thread_atom_nl" "lj thread_atom_nl"; do
+for c in "lj thread_atom" "eam cta_cell" "eam thread_atom_nl" "lj thread_atom_nl" "eam thread_atom"; do
   set -- $c
   rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAIT_ANY --kernel-trace --output-format csv -d $O/pmc_$1_$2_SQ1 -o out -- python3 $R/bench.py --pot $1 --method $2 --no-cpu-baseline --no-variants --no-target-line --steps 6 --warmup 2 > $O/pmc_$1_$2_SQ1.log 2>&1
   rocprofv3 --pmc SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_ANY SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --kernel-trace --output-format csv -d $O/pmc_$1_$2_SQ2 -o out -- python3 $R/bench.py --pot $1 --method $2 --no-cpu-baseline --no-variants --no-target-line --steps 6 --warmup 2 > $O/pmc_$1_$2_SQ2.log 2>&1

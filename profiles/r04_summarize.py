@@ -17,7 +17,7 @@ N = 2048000
 PATHS = [("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("lj", "cta_cell"), ("eam", "cta_cell"), ("eam", "thread_atom_nl"), ("eam", "thread_atom")]
 KERN = {("lj", "thread_atom"): ["LJ_Force_thread_atom<false, true>"], ("lj", "thread_atom_nl"): ["LJ_Force_nl_slabs<false>"], ("lj", "cta_cell"): ["LJ_Force_cta_cell_boxes<false>"],
         ("eam", "cta_cell"): ["EAM_Force_cta_brick<1", "EAM_Force_cta_brick<3"], ("eam", "thread_atom_nl"): ["EAM_Force_cta_brick<1", "EAM_Force_cta_brick<3"],
-        ("eam", "thread_atom"): ["EAM_Force_thread_atom<1", "EAM_Force_embed", "EAM_Force_thread_atom<3"]}
+        ("eam", "thread_atom"): ["EAM_Force_atom_brick<1", "EAM_Force_atom_brick<3"]}
 
 
 def stats_file(pot, meth):
@@ -39,7 +39,8 @@ def main():
     shutil.copy(os.path.join(F, "pmc_summary.json"), os.path.join(P, "r04_pmc_summary.json"))
     loop = {}
     for tag in ("plain_lj", "loopback_lj", "loopback_lj_handshake", "loopback_lj_overlap", "plain_eam", "loopback_eam", "loopback_eam_handshake", "loopback_eam_overlap",
-                "plain_lj_messages", "plain_eam_messages", "plain_eam_nl", "plain_eam_nl_messages", "plain_eam_nl_round3_kernel", "loopback_eam_nl_overlap"):
+                "plain_lj_messages", "plain_eam_messages", "plain_eam_nl", "plain_eam_nl_messages", "plain_eam_nl_round3_kernel", "loopback_eam_nl_overlap",
+                "plain_eam_thread_atom", "plain_eam_thread_atom_round2_kernel", "plain_eam_thread_atom_no_handover", "loopback_eam_thread_atom_overlap"):
         try:
             d = json.loads(open(os.path.join(F, tag + ".json")).read().strip().splitlines()[-1])
         except (OSError, IndexError, ValueError):
@@ -52,7 +53,8 @@ def main():
                       "loopback_*_handshake: COMD_HALO_HANDSHAKE=1, the exact-size handshake of round 1 (three host syncs per exchange); loopback_*_overlap: the sized protocol with -a 1 "
                       "(interior cells on a second stream during the exchange: the mode bench.py runs for N > 1).  [round 4] every loopback line carries the self-check of the sized "
                       "protocol (sized_matches_handshake: the same steps again with the handshake, bit for bit); plain_*_messages: COMD_HALO_MIRROR=0, the pack / unpack path of round 3 on the "
-                      "self-neighbour axes instead of the direct mirror; plain_eam_nl_round3_kernel: COMD_EAM_NL=lds, round 3's list kernel.")
+                      "self-neighbour axes instead of the direct mirror; plain_eam_nl_round3_kernel: COMD_EAM_NL=lds, round 3's list kernel; plain_eam_thread_atom*: -m thread_atom -e on the brick image "
+                      "(eam_atom_brick_kernels.h), with COMD_EAM_THREAD_ATOM=cell round 2's kernel, with COMD_EAM_ATOM_HANDOVER=0 pass 3 testing again.")
     json.dump(loop, open(os.path.join(P, "r04_rccl_loopback_bench.json"), "w"), indent=1)
 
     pmc = json.load(open(os.path.join(F, "pmc_summary.json")))
@@ -72,7 +74,7 @@ def main():
                          "--kernel-trace only; both in KiB).  Per MI355X_MICROARCH.md (HBM section) FETCH_SIZE under-reports a wide coalesced 16 B/lane stream by exactly 2x on gfx950 "
                          "and is uncalibrated for other widths; these kernels read through 64-byte scalar loads, 8-byte lane loads and 2-byte list loads, so the fetch side is given raw. "
                          "WRITE_SIZE is exact for streaming stores.  bench.py reports raw_fetch + write as `traffic`.  Every force kernel of the runs: profiles/r04_pmc_summary.json."}
-    for pot, meth in [("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("eam", "cta_cell"), ("eam", "thread_atom_nl")]:
+    for pot, meth in [("lj", "thread_atom"), ("lj", "thread_atom_nl"), ("eam", "cta_cell"), ("eam", "thread_atom_nl"), ("eam", "thread_atom")]:
         pre = KERN[(pot, meth)]
         fe, wr = per_launch(f"{pot}_{meth}", "FETCH_SIZE", pre), per_launch(f"{pot}_{meth}", "WRITE_SIZE", pre)
         if fe is None or wr is None:
@@ -154,7 +156,8 @@ def main():
     out.append("")
     for tag, names in (("lj_thread_atom", ["LJ_Force_thread_atom<false, true>"]), ("lj_thread_atom_nl", ["LJ_Force_nl_slabs<false>"]),
                        ("eam_cta_cell", ["EAM_Force_cta_brick<1, true, false, false>", "EAM_Force_cta_brick<3, true, false, false>"]),
-                       ("eam_thread_atom_nl", ["EAM_Force_cta_brick<1, true, false, true>", "EAM_Force_cta_brick<3, true, false, true>", "EAM_Force_cta_brick<0"])):
+                       ("eam_thread_atom_nl", ["EAM_Force_cta_brick<1, true, false, true>", "EAM_Force_cta_brick<3, true, false, true>", "EAM_Force_cta_brick<0"]),
+                       ("eam_thread_atom", ["EAM_Force_atom_brick<1", "EAM_Force_atom_brick<3"])):
         for nm in names:
             sq = {}
             for grp in ("SQ1", "SQ2", "TCC"):
@@ -173,12 +176,13 @@ def main():
     # non-force time per step and what the direct mirror of the self-neighbour axes bought (one rank: all three axes)
     out.append("## Step time outside the force evaluation (ms/step - force_evaluation_ms), one rank\n")
     out.append("| run | ms/step | force evaluation ms | non-force ms |\n|---|---|---|---|")
-    for tag in ("plain_lj", "plain_lj_messages", "plain_eam", "plain_eam_messages", "plain_eam_nl", "plain_eam_nl_messages", "plain_eam_nl_round3_kernel"):
+    for tag in ("plain_lj", "plain_lj_messages", "plain_eam", "plain_eam_messages", "plain_eam_nl", "plain_eam_nl_messages", "plain_eam_nl_round3_kernel",
+                "plain_eam_thread_atom", "plain_eam_thread_atom_round2_kernel", "plain_eam_thread_atom_no_handover"):
         if tag in loop:
             v = loop[tag]
             out.append(f"| {tag} | {v['ms_per_step']:.3f} | {v['force_evaluation_ms']:.3f} | {v['ms_per_step'] - v['force_evaluation_ms']:.3f} |")
     out.append("")
-    for tag in ("loopback_lj", "loopback_eam", "loopback_lj_overlap", "loopback_eam_overlap", "loopback_eam_nl_overlap"):
+    for tag in ("loopback_lj", "loopback_eam", "loopback_lj_overlap", "loopback_eam_overlap", "loopback_eam_nl_overlap", "loopback_eam_thread_atom_overlap"):
         if tag in loop and "sized_matches_handshake" in loop[tag]:
             out.append(f"* `{tag}`: sized_matches_handshake = {loop[tag]['sized_matches_handshake']}, eFinal/eInitial = {loop[tag].get('eFinal_over_eInitial')}")
     out.append("")
