@@ -1131,11 +1131,14 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    };
    const double lat = sim->latticeConstant > 0.0 ? sim->latticeConstant : 3.615;
    const double rc = sim->eam_pot.cutoff;
-   // a row per thread: the cutoff sphere at the lattice's density + 50 %, a multiple of 8 (an atom with more neighbours walks its stencil a second time)
-   int rows = ((int)(4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat) * 1.5) + 7) / 8 * 8;
+   // a row per thread (bytes: a neighbour is its offset inside its run of the image): the cutoff sphere at the lattice's density + 50 %, a multiple of 8 (an atom
+   // with more neighbours walks its stencil a second time); further down it gives up to a fifth of that when the LDS so freed buys a workgroup per CU in pass 1
+   const double inSphere = 4.18879020478639 * rc * rc * rc * 4.0 / (lat * lat * lat);
+   int rows = ((int)(inSphere * 1.5) + 7) / 8 * 8;
    if (rows < 32) rows = 32;
    if (rows > 128) rows = 128;
-   { const char* e = getenv("COMD_EAM_ATOM_ROWS"); if (e && atoi(e) >= 8 && atoi(e) <= 128) rows = atoi(e) / 8 * 8; }      // tests: rows that overflow
+   int rowsForced = 0;
+   { const char* e = getenv("COMD_EAM_ATOM_ROWS"); if (e && atoi(e) >= 8 && atoi(e) <= 128) rows = rowsForced = atoi(e) / 8 * 8; }      // tests: rows that overflow
    EamBrickArgs b;
    eamBrickGeometry(sim, false, &b);
    const double perCell = 4.0 / (lat * lat * lat) / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);      // atoms of a cell at the lattice's density
@@ -1156,7 +1159,7 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
          const int cap = eamBrickSizeImage(sim, b, st, false);
          const bool last = ey || sim->eam_pot.atomBrickBy || k == nShapes - 1;
          const int rt = rowThreadsOf(perCell * b.by * b.bz);
-         const size_t lds1 = eamAtomBrickLdsBytes(1, tableDoublesOf(1), cap, rows, rt), lds3 = eamAtomBrickLdsBytes(3, tableDoublesOf(3), cap, rows, rt);
+         const size_t lds1 = eamAtomBrickLdsBytes(1, tableDoublesOf(1), cap, rows, rt, true), lds3 = eamAtomBrickLdsBytes(3, tableDoublesOf(3), cap, rows, rt, true);
          if (last || (perCell * b.by * b.bz <= 1.05 * EAM_ATOM_BRICK_THREADS && lds1 <= 80 * 1024 && lds3 <= 80 * 1024)) {
             sim->eam_pot.atomBrickBy = b.by; sim->eam_pot.atomBrickBz = b.bz; sim->eam_pot.atomBrickImageCap = cap;
             break;
@@ -1166,18 +1169,28 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    b.by = sim->eam_pot.atomBrickBy; b.bz = sim->eam_pot.atomBrickBz;
    b.nby = ceilDiv(b.geom.g[1], b.by); b.nbz = ceilDiv(b.geom.g[2], b.bz);
    b.imageCap = sim->eam_pot.atomBrickImageCap;
-   b.rows = rows;
    b.listRounds = rowThreadsOf(perCell * b.by * b.bz);      // (EAM_Force_atom_brick reads its row threads here)
+   auto perCu = [&](size_t bytes) { return bytes > 160 * 1024 ? 0 : (int)(160 * 1024 / (((bytes + 1279) / 1280) * 1280)); };      // (the LDS is handed out in 1280-byte granules)
+   if (!rowsForced) {
+      const int least = ((int)(inSphere * 1.2) + 7) / 8 * 8;
+      int best = rows, bestWgs = perCu(eamAtomBrickLdsBytes(1, tableDoublesOf(1), b.imageCap, rows, b.listRounds, true));
+      for (int r = rows - 8; r >= least && r >= 32; r -= 8) {
+         const int wgs = perCu(eamAtomBrickLdsBytes(1, tableDoublesOf(1), b.imageCap, r, b.listRounds, true));
+         if (wgs > bestWgs) { bestWgs = wgs; best = r; }
+      }
+      rows = best;
+   }
+   b.rows = rows;
    if (!sim->eam_pot.brickStats) sim->eam_pot.brickStats = dalloc<int>(2);
    b.stats = sim->eam_pot.brickStats;
    b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
    { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
    // the rows pass 1 leaves for pass 3 (eam_atom_brick_kernels.h; COMD_EAM_ATOM_HANDOVER=0: pass 3 tests again, A/B runs)
-   if (!(getenv("COMD_EAM_ATOM_HANDOVER") && atoi(getenv("COMD_EAM_ATOM_HANDOVER")) == 0)) {
+   if (!(getenv("COMD_EAM_ATOM_HANDOVER") && atoi(getenv("COMD_EAM_ATOM_HANDOVER")) == 0) && rows <= 16 * EAM_ATOM_ROW_CHUNKS) {
       const size_t nBricks = (size_t)b.geom.g[0] * b.nby * b.nbz;
       if (!sim->eam_pot.atomRows) {
-         sim->eam_pot.atomRows = dalloc<unsigned>(nBricks * (rows / 8) * 256 * 4, false);
-         sim->eam_pot.atomRowCount = dalloc<unsigned short>(nBricks * 256, false);
+         sim->eam_pot.atomRows = dalloc<unsigned>(nBricks * EAM_ATOM_ROW_CHUNKS * 256 * 4, false);
+         sim->eam_pot.atomRowCount = dalloc<unsigned short>(nBricks * 256 * 2, false);      // (a 32-bit word per atom: the three runs' counts)
          sim->eam_pot.atomBrickSel = dalloc<unsigned long long>((size_t)sim->boxes.nLocalBoxes, false);
          HIP_CHECK(hipMemsetAsync(sim->eam_pot.atomBrickSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(unsigned long long), st));
       }
@@ -1197,7 +1210,10 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
       ForceTimer aux(sim, st, 1);
       hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(num_cells, 256)), dim3(256), 0, st, cells_list, num_cells, sim->eam_pot.cellSel, b.tag);
    }
-   const size_t lds = eamAtomBrickLdsBytes(STEP, tableDoublesOf(STEP), b.imageCap, b.rows, b.listRounds);
+   // pass 3 keeps rows in the LDS only when it has none to read: what they would take is the third workgroup of a CU
+   b.listQuads = (STEP == 3 && b.rowsG) ? 0 : 1;
+   size_t lds = eamAtomBrickLdsBytes(STEP, tableDoublesOf(STEP), b.imageCap, b.rows, b.listRounds, b.listQuads != 0);
+   { const char* e = getenv("COMD_EAM_ATOM_LDS_PAD"); if (e) lds += (size_t)atoi(e); }      // experiments: fewer workgroups per CU
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: thread_atom needs %zu bytes of LDS for this box\n", lds); exit(-1); }
    const int grid = group ? sim->eam_pot.brickCount[group - 1] : b.geom.g[0] * b.nby * b.nbz;
    if (grid <= 0) return;

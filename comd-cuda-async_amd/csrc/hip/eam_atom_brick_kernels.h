@@ -20,19 +20,21 @@
 
 #define EAM_ATOM_BRICK_THREADS 256
 
-// a thread's row: `rows` numbers + 6 of padding (a group of four candidates is appended before the row's end is looked at; an odd count of dwords for rows % 8 == 0)
-__host__ __device__ static inline int eamAtomBrickRowStride(int rows) { return rows + 6; }
+#define EAM_ATOM_ROW_CHUNKS 4            // 16-byte chunks of a row handed from pass 1 to pass 3: rows of up to 64 bytes
+// a thread's row: `rows` bytes + 4 of padding (a group of four candidates is appended before the row's end is looked at; an odd count of dwords for rows % 8 == 0)
+__host__ __device__ static inline int eamAtomBrickRowStride(int rows) { return rows + 4; }
 // LDS of one workgroup: tables | image (+ F' in pass 3) | offsets, cell ids, scalars, selected cells (eamBrickSharedBytes) | own-atom prefix | rows
 // (rowThreads: the threads that take atoms -- whole waves, enough for the brick's atoms; EamBrickArgs.listRounds carries the number to the kernel.  The
 // other waves of the 256 only help to stage: rows for threads that never have an atom would cost the second workgroup of a CU.)
-static inline size_t eamAtomBrickLdsBytes(int step, size_t tableDoubles, int imageCap, int rows, int rowThreads)
+// (ldsRows: pass 1 always; pass 3 only when it cannot read the rows of pass 1)
+static inline size_t eamAtomBrickLdsBytes(int step, size_t tableDoubles, int imageCap, int rows, int rowThreads, bool ldsRows)
 {
    return eamTableBytesAligned(tableDoubles) + eamBrickSharedBytes(step, imageCap) + (68 + 64) * sizeof(int)
-          + (size_t)rowThreads * eamAtomBrickRowStride(rows) * sizeof(unsigned short);
+          + (ldsRows ? (size_t)rowThreads * eamAtomBrickRowStride(rows) + 16 : 0);
 }
 
 template <int STEP, bool LDS_TABLES, bool SPLINE, bool CLAMP>
-__global__ __launch_bounds__(EAM_ATOM_BRICK_THREADS, 2)
+__global__ __launch_bounds__(EAM_ATOM_BRICK_THREADS, 3)
 void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
 {
    static_assert(STEP == 1 || STEP == 3, "passes 1 and 3");
@@ -55,7 +57,7 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    int* sOwn = (int*)(sList + 64);                           // [65] atoms of the selected cells before cell k of that list
    int* sFull = sOwn + 68;                                   // [64] atoms of the brick before brick cell c, selected or not (the hand-over's atom index)
    const int strideL = eamAtomBrickRowStride(b.rows);
-   unsigned short* __restrict__ myRow = (unsigned short*)(sFull + 64) + (size_t)tid * strideL;
+   unsigned char* __restrict__ myRow = (unsigned char*)(sFull + 64) + (size_t)tid * strideL;
 
    // ---- the brick and its selected cells (as EAM_Force_cta_brick) ---------------------------------------------------------------------------
    const int gx = b.geom.g[0], gy = b.geom.g[1], gz = b.geom.g[2];
@@ -206,24 +208,26 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    // own atom t of the brick -> its cell (k-th selected, brick cell cl) and its number in the cell
    const int nOwn = uniform(sOwn[nSel]);
    const int rowThreads = b.listRounds;                      // threads that take atoms (whole waves)
+   const bool ldsRows = STEP == 1 || b.listQuads != 0;       // pass 3 has rows in the LDS only where the launcher found no hand-over to read (else the LDS they would take buys a workgroup per CU)
    auto ownAtom = [&](const int t, int& cl, int& ia) {
       int k = 0;
       for (int s = 1; s < nSel; ++s) k += t >= sOwn[s] ? 1 : 0;
       cl = sList[k]; ia = t - sOwn[k];
    };
    // the selection is written beside the cells whose rows this launch leaves (pass 1); pass 3 asks for the first round's rows now, a staging away from their use
-   constexpr int CH = 6;                                     // chunks of 8 numbers asked for ahead (48 neighbours; the FCC count inside 4.95 A is 42)
+   constexpr int CH = EAM_ATOM_ROW_CHUNKS;
    uint4 pre[CH];
-   unsigned preN = 0xffffu;
+   unsigned preN = 0xffffffffu;
    unsigned long long preSel = ~selMask;
-   const uint4* __restrict__ rowsG4 = reinterpret_cast<const uint4*>(b.rowsG) + (size_t)bid * (b.rows >> 3) * 256;      // [brick][rows / 8 chunks][256 atoms]
+   const uint4* __restrict__ rowsG4 = reinterpret_cast<const uint4*>(b.rowsG) + (size_t)bid * CH * 256;      // [brick][chunk][256 atoms]
+   unsigned* __restrict__ rowCountG = reinterpret_cast<unsigned*>(b.rowCountG) + (size_t)bid * 256;        // [brick][256 atoms] n0 | n1 << 8 | n2 << 16
 #pragma unroll
    for (int c = 0; c < CH; ++c) pre[c] = make_uint4(0u, 0u, 0u, 0u);
    if (STEP == 3 && b.rowsG && (wave << 6) < rowThreads && (wave << 6) < nOwn) {
       int cl, ia; ownAtom((wave << 6) + lane < nOwn ? (wave << 6) + lane : nOwn - 1, cl, ia);
       const int full = sFull[cl] + ia;
       if (full < 256) {
-         preN = b.rowCountG[(size_t)bid * 256 + full];
+         preN = rowCountG[full];
          preSel = b.brickSel[sBox[1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1))]];
 #pragma unroll
          for (int c = 0; c < CH; ++c) pre[c] = rowsG4[c * 256 + full];
@@ -258,7 +262,7 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    __syncthreads();
 
    if (b.debug & 4) return;
-   // ---- thread t takes own atom t, t + 256, ... ----------------------------------------------------------------------------------------------------
+   // ---- thread t takes own atom t, t + rowThreads, ... ---------------------------------------------------------------------------------------------
    if ((wave << 6) >= rowThreads) return;
    for (int base = wave << 6; base < nOwn; base += rowThreads) {      // (wave-uniform: a wave whose 64 atoms do not exist has nothing to do)
       const bool have = base + lane < nOwn;
@@ -267,104 +271,16 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
       const int yh = cl % b.by + 1, zh = cl / b.by + 1, hc = 1 + 3 * (yh + HY * zh);
       const int iBox = sBox[hc], recI = sOff[hc] + ia;
       const bool firstRound = base == (wave << 6);
-      // pass 3: the rows of pass 1, when every atom of the wave has one that was numbered against this image
-      bool handed = false;
-      if (STEP == 3 && firstRound && __builtin_amdgcn_ballot_w64(preN != 0xffffu && preSel == selMask) == ~0ull) {
-         handed = true;
-         unsigned* __restrict__ rowW = reinterpret_cast<unsigned*>(myRow);
-#pragma unroll
-         for (int c = 0; c < CH; ++c) { rowW[4 * c] = pre[c].x; rowW[4 * c + 1] = pre[c].y; rowW[4 * c + 2] = pre[c].z; rowW[4 * c + 3] = pre[c].w; }
-         for (int c = CH; c < (int)(preN + 7u) >> 3; ++c) {      // a row beyond 48 numbers: blocking
-            const uint4 v = rowsG4[c * 256 + sFull[cl] + ia];
-            rowW[4 * c] = v.x; rowW[4 * c + 1] = v.y; rowW[4 * c + 2] = v.z; rowW[4 * c + 3] = v.w;
-         }
-      }
       const real_t xi = sp[REC * recI], yi = sp[REC * recI + 1], zi = sp[REC * recI + 2];
       const real_t dfi = (STEP == 3) ? sd[recI] : R(0.0);
+      // the three runs of the cell's stencil (rows yh-1 .. yh+1 of a z plane lie back to back)
+      const int rs0 = sOff[3 * ((yh - 1) + HY * (zh - 1))], len0 = sOff[3 * ((yh + 1) + HY * (zh - 1)) + 3] - rs0;
+      const int rs1 = sOff[3 * ((yh - 1) + HY * zh)],       len1 = sOff[3 * ((yh + 1) + HY * zh) + 3] - rs1;
+      const int rs2 = sOff[3 * ((yh - 1) + HY * (zh + 1))], len2 = sOff[3 * ((yh + 1) + HY * (zh + 1)) + 3] - rs2;
 
-      // TEST: the three runs of the cell's stencil (rows yh-1 .. yh+1 of a z plane lie back to back).  Four candidates per group, the records of the NEXT
-      // group requested before the current one is tested (two register sets, ping-pong): the walk lives on LDS latency, and a brick workgroup's waves are few.
-      // The groups every lane of the wave has whole are walked without masks, addresses as immediate offsets from one running pointer; what is left of the
-      // longer runs takes the masked form (a candidate past the end names the atom itself: no hit).  The row's end is looked at once per group (its padding takes the
-      // group).  Only the middle plane holds the atom itself.
-      unsigned short* w = myRow;
-      unsigned short* const wEnd = myRow + b.rows;
-      bool over = false;                                    // more hits than the row holds
-      constexpr int G = 4;
-#pragma unroll 1
-      for (int p = ((b.debug & 1) || handed) ? 3 : 0; p < 3; ++p) {
-         const int rs = sOff[3 * ((yh - 1) + HY * (zh - 1 + p))], len = sOff[3 * ((yh + 1) + HY * (zh - 1 + p)) + 3] - rs;
-         real_t ax[G], ay[G], az[G], cx[G], cy[G], cz[G];
-         int whole = len / (2 * G);
-#pragma unroll
-         for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(whole, m); whole = o < whole ? o : whole; }
-         whole = uniform(whole);
-         int u = 0;
-         if (whole > 0) {
-            const real_t* __restrict__ q = sp + REC * rs;
-            auto askU = [&](const real_t* __restrict__ src, real_t (&X)[G], real_t (&Y)[G], real_t (&Z)[G]) {
-#pragma unroll
-               for (int g = 0; g < G; ++g) { X[g] = src[REC * g]; Y[g] = src[REC * g + 1]; Z[g] = src[REC * g + 2]; }
-            };
-            auto testU = [&](const int r0, const bool self, const real_t (&X)[G], const real_t (&Y)[G], const real_t (&Z)[G]) {
-#pragma unroll
-               for (int g = 0; g < G; ++g) {
-                  const real_t dx = xi - X[g], dy = yi - Y[g], dz = zi - Z[g];
-                  bool hit = dx * dx + dy * dy + dz * dz <= a.rc2;
-                  if (self) hit = hit && r0 + g != recI;
-                  *w = (unsigned short)(r0 + g);             // (unconditional: a candidate that is no hit is overwritten by the next; no exec-mask round trip per candidate)
-                  w += hit ? 1 : 0;
-               }
-               over = over || w > wEnd; w = w > wEnd ? wEnd : w;
-            };
-            askU(q, ax, ay, az);
-            if (p == 1) {
-               for (int it = 0; it < whole; ++it) {
-                  askU(q + REC * G, cx, cy, cz); testU(rs + u, true, ax, ay, az);
-                  askU(q + 2 * REC * G, ax, ay, az); testU(rs + u + G, true, cx, cy, cz);      // (the last request reads past the whole groups, inside the image or its neighbours in the LDS: dropped)
-                  q += 2 * REC * G; u += 2 * G;
-               }
-            } else {
-               for (int it = 0; it < whole; ++it) {
-                  askU(q + REC * G, cx, cy, cz); testU(rs + u, false, ax, ay, az);
-                  askU(q + 2 * REC * G, ax, ay, az); testU(rs + u + G, false, cx, cy, cz);
-                  q += 2 * REC * G; u += 2 * G;
-               }
-            }
-         }
-         auto ask = [&](const int v, real_t (&X)[G], real_t (&Y)[G], real_t (&Z)[G]) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-               const int r = v + g < len ? rs + v + g : recI;
-               X[g] = sp[REC * r]; Y[g] = sp[REC * r + 1]; Z[g] = sp[REC * r + 2];
-            }
-         };
-         auto test = [&](const int v, const real_t (&X)[G], const real_t (&Y)[G], const real_t (&Z)[G]) {
-#pragma unroll
-            for (int g = 0; g < G; ++g) {
-               const int r = v + g < len ? rs + v + g : recI;
-               const real_t dx = xi - X[g], dy = yi - Y[g], dz = zi - Z[g];
-               const bool hit = dx * dx + dy * dy + dz * dz <= a.rc2 && r != recI;
-               *w = (unsigned short)r;
-               w += hit ? 1 : 0;
-            }
-            over = over || w > wEnd; w = w > wEnd ? wEnd : w;
-         };
-         for (; u < len; u += G) { ask(u, ax, ay, az); test(u, ax, ay, az); }
-      }
-      int n = handed ? (int)preN : over ? b.rows + 1 : (int)(w - myRow);
-      if (STEP == 1 && b.rowsG && firstRound && have) {      // leave the row for pass 3 (a row that outgrew its capacity: marked, pass 3 tests again)
-         const int full = sFull[cl] + ia;
-         if (full < 256) {
-            b.rowCountG[(size_t)bid * 256 + full] = (unsigned short)(n > b.rows ? 0xffff : n);
-            uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + (size_t)bid * (b.rows >> 3) * 256 + full;
-            const unsigned* __restrict__ rowR = reinterpret_cast<const unsigned*>(myRow);
-            for (int c = 0; c < (n > b.rows ? 0 : (n + 7) >> 3); ++c) dst[c * 256] = make_uint4(rowR[4 * c], rowR[4 * c + 1], rowR[4 * c + 2], rowR[4 * c + 3]);
-         }
-      }
-      // EVALUATE: two pairs per trip, branch-free; a missing second pair is evaluated at r = cutoff and weighted 0
       real_t fx = R(0.0), fy = R(0.0), fz = R(0.0), e = R(0.0), rb = R(0.0);
-      auto evalTrip = [&](const int j0, const int j1, const bool h1) {
+      // two pairs per trip, branch-free; a missing second pair is evaluated at r = cutoff and weighted 0
+      auto evalTrip = [&](const int j0, const int j1, const bool h1) __attribute__((always_inline)) {
          const real_t* r0 = sp + REC * j0; const real_t* r1 = sp + REC * j1;
          const real_t dx0 = xi - r0[0], dy0 = yi - r0[1], dz0 = zi - r0[2];
          const real_t dx1 = xi - r1[0], dy1 = yi - r1[1], dz1 = zi - r1[2];
@@ -398,24 +314,117 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          fx -= dphi0 * dx0; fy -= dphi0 * dy0; fz -= dphi0 * dz0;
          fx -= dphi1 * dx1; fy -= dphi1 * dy1; fz -= dphi1 * dz1;
       };
-      if (b.debug & 2) n = 0;
-      if (n <= b.rows) {
-         for (int u = 0; u < n; u += 2) {
-            const bool h1 = u + 1 < n;
-            evalTrip(myRow[u], h1 ? (int)myRow[u + 1] : recI, h1);
+      // A ROW is bytes: the offsets of the hits inside their run, run after run, each run's part starting on an even byte -- a trip (two bytes) lies in one run:
+      // bytes [0, n0) run 0, [S1, S1 + n1) run 1, [S2, S2 + n2) run 2 with S1 = n0 rounded up to even, S2 = S1 + n1 rounded up
+      auto tripOf = [&](const int u, const unsigned pair, const int S1, const int S2, const int end0, const int end1, const int end2) __attribute__((always_inline)) {
+         const int rsP = u >= S2 ? rs2 : u >= S1 ? rs1 : rs0, endP = u >= S2 ? end2 : u >= S1 ? end1 : end0;
+         const bool h1 = u + 1 < endP;
+         evalTrip(rsP + (int)(pair & 0xffu), h1 ? rsP + (int)((pair >> 8) & 0xffu) : recI, h1);
+      };
+      // the walk without rows: test and evaluate as it goes (an atom whose row overflowed; pass 3 without a row to read)
+      auto directWalk = [&]() __attribute__((always_inline)) {
+         const int l01 = len0 + len1, total = l01 + len2;
+#pragma unroll 1
+         for (int t = 0; t < total; ++t) {
+            const int r = t < len0 ? rs0 + t : t < l01 ? rs1 + (t - len0) : rs2 + (t - l01);
+            const real_t ax = xi - sp[REC * r], ay = yi - sp[REC * r + 1], az = zi - sp[REC * r + 2];
+            if (ax * ax + ay * ay + az * az <= a.rc2 && r != recI) evalTrip(r, recI, false);
          }
+      };
+      // pass 3: the rows of pass 1, when every atom of the wave has one that was numbered against this image
+      bool handed = false;
+      if (STEP == 3 && firstRound && __builtin_amdgcn_ballot_w64(preN != 0xffffffffu && preSel == selMask) == ~0ull) {
+         handed = true;
+         const int n0 = (int)(preN & 0xffu), n1 = (int)((preN >> 8) & 0xffu), n2 = (int)((preN >> 16) & 0xffu);
+         const int S1 = (n0 + 1) & ~1, S2 = S1 + ((n1 + 1) & ~1), total = (b.debug & 2) ? 0 : S2 + n2;
+         const unsigned wr[4 * CH] = { pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w,
+                                       pre[2].x, pre[2].y, pre[2].z, pre[2].w, pre[3].x, pre[3].y, pre[3].z, pre[3].w };
+#pragma unroll
+         for (int tr = 0; tr < 8 * CH; ++tr)               // (unrolled: the words sit in registers; a trip no lane has is a skipped branch)
+            if (2 * tr < total) tripOf(2 * tr, (tr & 1) ? wr[tr >> 1] >> 16 : wr[tr >> 1], S1, S2, n0, S1 + n1, total);
+      } else if (STEP == 3 && !ldsRows) {
+         directWalk();
       } else {
-         // more neighbours than a row holds (a density far above the lattice's): this atom walks its stencil again and evaluates as it goes -- thread_atom
-         // is the method without a limit
-#pragma unroll 1
+         // TEST.  Four candidates per group, the records of the NEXT group requested before the current one is tested (two register sets, ping-pong): the walk
+         // lives on LDS latency, and a brick workgroup's waves are few.  The groups every lane of the wave has whole are walked without masks, addresses as
+         // immediate offsets from one running pointer; what is left of the longer runs takes the masked form (a candidate past the end names the atom itself: no
+         // hit).  Every candidate's offset is written at the row's end and the end advanced past a hit (no exec-mask round trip per candidate); the capacity is
+         // looked at once per group (the row's padding takes the group).  Only the middle plane holds the atom itself.
+         unsigned char* w = myRow;
+         unsigned char* const wEnd = myRow + b.rows;
+         bool over = len0 > 256 || len1 > 256 || len2 > 256;      // an offset would not fit a byte: no row
+         int cnt[3] = { 0, 0, 0 };
+         constexpr int G = 4;
+#pragma unroll
          for (int p = 0; p < 3; ++p) {
-            const int rs = sOff[3 * ((yh - 1) + HY * (zh - 1 + p))], re = sOff[3 * ((yh + 1) + HY * (zh - 1 + p)) + 3];
-#pragma unroll 1
-            for (int r = rs; r < re; ++r) {
-               const real_t ax = xi - sp[REC * r], ay = yi - sp[REC * r + 1], az = zi - sp[REC * r + 2];
-               if (ax * ax + ay * ay + az * az <= a.rc2 && r != recI) evalTrip(r, recI, false);
+            const int rs = p == 0 ? rs0 : p == 1 ? rs1 : rs2, len = (b.debug & 1) ? 0 : p == 0 ? len0 : p == 1 ? len1 : len2;
+            unsigned char* const wStart = w;
+            real_t ax[G], ay[G], az[G], cx[G], cy[G], cz[G];
+            int whole = len / (2 * G);
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(whole, m); whole = o < whole ? o : whole; }
+            whole = uniform(whole);
+            int u = 0;
+            if (whole > 0) {
+               const real_t* __restrict__ q = sp + REC * rs;
+               auto askU = [&](const real_t* __restrict__ src, real_t (&X)[G], real_t (&Y)[G], real_t (&Z)[G]) {
+#pragma unroll
+                  for (int g = 0; g < G; ++g) { X[g] = src[REC * g]; Y[g] = src[REC * g + 1]; Z[g] = src[REC * g + 2]; }
+               };
+               auto testU = [&](const int u0, const real_t (&X)[G], const real_t (&Y)[G], const real_t (&Z)[G]) {
+#pragma unroll
+                  for (int g = 0; g < G; ++g) {
+                     const real_t dx = xi - X[g], dy = yi - Y[g], dz = zi - Z[g];
+                     bool hit = dx * dx + dy * dy + dz * dz <= a.rc2;
+                     if (p == 1) hit = hit && rs + u0 + g != recI;
+                     *w = (unsigned char)(u0 + g);
+                     w += hit ? 1 : 0;
+                  }
+                  over = over || w > wEnd; w = w > wEnd ? wEnd : w;
+               };
+               askU(q, ax, ay, az);
+               for (int it = 0; it < whole; ++it) {
+                  askU(q + REC * G, cx, cy, cz); testU(u, ax, ay, az);
+                  askU(q + 2 * REC * G, ax, ay, az); testU(u + G, cx, cy, cz);      // (the last request reads past the whole groups, inside the image or its neighbours in the LDS: dropped)
+                  q += 2 * REC * G; u += 2 * G;
+               }
+            }
+            for (; u < len; u += G) {
+#pragma unroll
+               for (int g = 0; g < G; ++g) {
+                  const int r = u + g < len ? rs + u + g : recI;
+                  ax[g] = sp[REC * r]; ay[g] = sp[REC * r + 1]; az[g] = sp[REC * r + 2];
+               }
+#pragma unroll
+               for (int g = 0; g < G; ++g) {
+                  const int r = u + g < len ? rs + u + g : recI;
+                  const real_t dx = xi - ax[g], dy = yi - ay[g], dz = zi - az[g];
+                  const bool hit = dx * dx + dy * dy + dz * dz <= a.rc2 && r != recI;
+                  *w = (unsigned char)(u + g);
+                  w += hit ? 1 : 0;
+               }
+               over = over || w > wEnd; w = w > wEnd ? wEnd : w;
+            }
+            cnt[p] = (int)(w - wStart);
+            if (p < 2) w += cnt[p] & 1;                       // the next run's part starts on an even byte
+         }
+         over = over || w > wEnd;
+         const int n0 = cnt[0], n1 = cnt[1], n2 = cnt[2];
+         const int S1 = (n0 + 1) & ~1, S2 = S1 + ((n1 + 1) & ~1), total = S2 + n2;
+         if (STEP == 1 && b.rowsG && firstRound && have) {      // leave the row for pass 3 (a row that outgrew its capacity: marked, pass 3 walks again)
+            const int full = sFull[cl] + ia;
+            if (full < 256) {
+               rowCountG[full] = over ? 0xffffffffu : (unsigned)n0 | ((unsigned)n1 << 8) | ((unsigned)n2 << 16);
+               uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + (size_t)bid * CH * 256 + full;
+               const unsigned* __restrict__ rowR = reinterpret_cast<const unsigned*>(myRow);
+               for (int c = 0; c < (over ? 0 : (total + 15) >> 4); ++c) dst[c * 256] = make_uint4(rowR[4 * c], rowR[4 * c + 1], rowR[4 * c + 2], rowR[4 * c + 3]);
             }
          }
+         // EVALUATE
+         if (over) directWalk();      // more neighbours than a row holds (a density far above the lattice's): thread_atom is the method without a limit
+         else
+            for (int u = 0; u < ((b.debug & 2) ? 0 : total); u += 2)
+               tripOf(u, *reinterpret_cast<const unsigned short*>(myRow + u), S1, S2, n0, S1 + n1, total);
       }
       if (!have) continue;
       const size_t iOff = (size_t)iBox * a.cap + ia;
