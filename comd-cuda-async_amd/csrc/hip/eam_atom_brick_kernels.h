@@ -6,14 +6,22 @@
 //   * a workgroup owns a brick of 1 x BY x BZ link cells (default 1 x 4 x 4) and stages the 3 x (BY + 2) x (BZ + 2) cells around it ONCE into the LDS, densely
 //     packed, z-y-x order (the staging of eam_brick_kernels.h: the stencil of a cell is three contiguous runs of records);
 //   * thread t takes the brick's t-th atom and works in two phases.  TEST: walk the three runs of its cell's stencil -- lanes of one cell read the same record
-//     (an LDS broadcast) -- and append the numbers of the records inside the cutoff to a row of its own in the LDS (16-bit numbers, 132-byte stride: the rows of
-//     a wave's lanes start on distinct banks).  EVALUATE: walk that row, two pairs per trip, branch-free inside the trip.  The divergence that is left is the
-//     row LENGTH (42 +- a few at 80^3), not the acceptance rate;
-//   * pass 1 leaves the rows in memory, [brick][chunk of 8 numbers][atom of the brick] 16-byte elements (a wave's stores are dense KBs; the atom's index counts
-//     through ALL cells of the brick, selected or not, so launches over different cell lists never write the same element), and the selection it staged the
-//     brick under beside every cell.  Pass 3 asks for an atom's row while the block is being staged and skips the TEST phase when the cell was staged under the
-//     same selection (the numbers index the image, whose composition depends on the selection) -- otherwise it tests again: a launch over any cell list is
-//     complete in itself, the hand-over is an optimisation the two passes need not agree on.
+//     (an LDS broadcast) -- and append the records inside the cutoff to a row of its own in the LDS: one BYTE per neighbour, its offset inside its run (a
+//     run is 9 cells, ~95 records; an atom with a run of more than 256 walks without a row), the three runs' parts back to back, each on an even byte; 60-byte
+//     stride, an odd count of dwords: the rows of a wave's lanes start on distinct banks.  EVALUATE: walk that row, two pairs per trip, branch-free inside
+//     the trip.  The divergence that is left is the row LENGTH (42 +- a few at 80^3), not the acceptance rate;
+//   * pass 1 leaves the rows in memory, [brick][16-byte chunk][atom of the brick] (a wave's stores are dense KBs; the atom's index counts through ALL cells of
+//     the brick, selected or not, so launches over different cell lists never write the same element), the three counts beside them, and the selection it
+//     staged the brick under beside every cell.  Pass 3 asks for an atom's row (64 bytes: four registers of four) while the block is being staged and, when
+//     every atom of the wave has a row numbered against this image (the cell was staged under the same selection: the offsets index the image, whose
+//     composition depends on it), evaluates STRAIGHT FROM THE REGISTERS -- no TEST phase, and no rows in pass 3's LDS at all.  A wave that finds anything
+//     else walks its stencils again, testing and evaluating as it goes (slow, rare: a launch over any cell list is complete in itself, the hand-over is an
+//     optimisation the two passes need not agree on); when the launcher knows there is nothing to read (COMD_EAM_ATOM_HANDOVER=0, rows beyond 64 bytes) pass 3
+//     gets rows in the LDS and works as pass 1 does;
+//   * the LDS decides the occupancy, and the occupancy the speed (the kernel issues 180 VALU instructions per atom in the two passes where cta_cell's brick
+//     kernel issues 235, and waits for the LDS): byte rows, rows only for the waves that take atoms (192 threads for a brick's 168 atoms; the fourth wave helps
+//     to stage), none in pass 3 -- 52 KB and 47 KB per workgroup at 80^3, THREE workgroups per CU in both passes (16-bit rows and rows in pass 3: two, 1.50 ms
+//     per force evaluation instead of 1.20).
 // A brick whose block outgrows the image takes the streaming form (eamCellDirect, a wave per cell) -- counted in stats[1], the host re-sizes the image.
 #pragma once
 #include "eam_brick_kernels.h"
