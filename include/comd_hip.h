@@ -212,7 +212,7 @@ typedef struct SimGpuSt {
                                         * (the size both ends of a halo message agreed on beforehand, see CommTransport.sendrecv2sized) */
    void*        timing;                /* comdForceTiming*: event pool of this simulation, NULL = off */
    real_t       latticeConstant;       /* GpuConfig.latticeConstant (0: 3.615): density estimate behind the LDS sizing of the cell kernels */
-   int          fuseEmbed;             /* host switch, default 0: with method CTA_CELL eamForce1Gpu[Async] also does the work of eamForce2Gpu[Async] for the
+   int          fuseEmbed;             /* host switch, default 0: with method CTA_CELL (and the list method on brick rows, and THREAD_ATOM on the brick image) eamForce1Gpu[Async] also does the work of eamForce2Gpu[Async] for the
                                         * cells it covers (F(rhobar), F'(rhobar) need nothing but the atom's own rhobar) and eamForce2Gpu[Async] returns at
                                         * once -- same e[], dfEmbed[] after the pair of calls, one launch fewer */
    /* scan scratch of the reference-side adapter (include/comd_hip_shim.h comdShimOffsets): the reference's per-face partial_sums arrays hold nCells ints,
