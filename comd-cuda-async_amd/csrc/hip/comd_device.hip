@@ -1144,12 +1144,15 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    const double perCell = 4.0 / (lat * lat * lat) / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);      // atoms of a cell at the lattice's density
    // the threads that take atoms: whole waves for the brick's atoms + 8 % (a fuller brick's threads take a second atom)
    auto rowThreadsOf = [&](double atoms) { int t = ((int)(atoms * 1.08) + 63) / 64 * 64; return t < 64 ? 64 : t > EAM_ATOM_BRICK_THREADS ? EAM_ATOM_BRICK_THREADS : t; };
-   // The brick: as many atoms as the workgroup has threads, the block within the 128 cells the staging covers, two workgroups per CU (80 KB of LDS each) in
+   // The brick: as many atoms as the workgroup has threads, the block within the 192 cells the staging covers, two workgroups per CU (80 KB of LDS each) in
    // both passes.  Tried in this order; COMD_EAM_ATOM_BRICK="by,bz" overrides.  Fixed by the first launch, the image is sized again when bricks outgrow it.
+   const bool handOver = !(getenv("COMD_EAM_ATOM_HANDOVER") && atoi(getenv("COMD_EAM_ATOM_HANDOVER")) == 0) && rows <= 16 * EAM_ATOM_ROW_CHUNKS;
    if (!sim->eam_pot.atomBrickBy || !sim->eam_pot.atomBrickImageCap) {
+      // (larger bricks stage fewer cells per atom and fill six waves -- and are slower: 1 x 5 x 5 1.39 ms, 1 x 4 x 6 1.42, 1 x 5 x 6 1.68 against 1.21 at 80^3; two large
+      //  workgroups per CU overlap one's staging with the other's arithmetic less than three small ones)
       static const int shapes[][2] = { { 4, 4 }, { 4, 3 }, { 4, 2 }, { 2, 2 }, { 2, 1 }, { 1, 1 } };
       int ey = 0, ez = 0;
-      { const char* e = getenv("COMD_EAM_ATOM_BRICK"); if (!(e && sscanf(e, "%d,%d", &ey, &ez) == 2 && ey >= 1 && ez >= 1 && 3 * (ey + 2) * (ez + 2) <= EAM_BRICK_MAX_CELLS && ey * ez <= 64)) ey = ez = 0; }
+      { const char* e = getenv("COMD_EAM_ATOM_BRICK"); if (!(e && sscanf(e, "%d,%d", &ey, &ez) == 2 && ey >= 1 && ez >= 1 && 3 * (ey + 2) * (ez + 2) <= EAM_ATOM_MAX_CELLS && ey * ez <= 64)) ey = ez = 0; }
       const int nShapes = (int)(sizeof shapes / sizeof shapes[0]);
       for (int k = sim->eam_pot.atomBrickBy ? nShapes - 1 : 0; k < nShapes; ++k) {
          if (sim->eam_pot.atomBrickBy) { b.by = sim->eam_pot.atomBrickBy; b.bz = sim->eam_pot.atomBrickBz; }      // (re-sizing: the shape stays)
@@ -1159,7 +1162,7 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
          const int cap = eamBrickSizeImage(sim, b, st, false);
          const bool last = ey || sim->eam_pot.atomBrickBy || k == nShapes - 1;
          const int rt = rowThreadsOf(perCell * b.by * b.bz);
-         const size_t lds1 = eamAtomBrickLdsBytes(1, tableDoublesOf(1), cap, rows, rt, true), lds3 = eamAtomBrickLdsBytes(3, tableDoublesOf(3), cap, rows, rt, true);
+         const size_t lds1 = eamAtomBrickLdsBytes(1, tableDoublesOf(1), cap, rows, rt, true), lds3 = eamAtomBrickLdsBytes(3, tableDoublesOf(3), cap, rows, rt, !handOver);
          if (last || (perCell * b.by * b.bz <= 1.05 * EAM_ATOM_BRICK_THREADS && lds1 <= 80 * 1024 && lds3 <= 80 * 1024)) {
             sim->eam_pot.atomBrickBy = b.by; sim->eam_pot.atomBrickBz = b.bz; sim->eam_pot.atomBrickImageCap = cap;
             break;
@@ -1186,11 +1189,11 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
    { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
    // the rows pass 1 leaves for pass 3 (eam_atom_brick_kernels.h; COMD_EAM_ATOM_HANDOVER=0: pass 3 tests again, A/B runs)
-   if (!(getenv("COMD_EAM_ATOM_HANDOVER") && atoi(getenv("COMD_EAM_ATOM_HANDOVER")) == 0) && rows <= 16 * EAM_ATOM_ROW_CHUNKS) {
+   if (handOver && rows <= 16 * EAM_ATOM_ROW_CHUNKS) {
       const size_t nBricks = (size_t)b.geom.g[0] * b.nby * b.nbz;
       if (!sim->eam_pot.atomRows) {
-         sim->eam_pot.atomRows = dalloc<unsigned>(nBricks * EAM_ATOM_ROW_CHUNKS * 256 * 4, false);
-         sim->eam_pot.atomRowCount = dalloc<unsigned short>(nBricks * 256 * 2, false);      // (a 32-bit word per atom: the three runs' counts)
+         sim->eam_pot.atomRows = dalloc<unsigned>(nBricks * EAM_ATOM_ROW_CHUNKS * EAM_ATOM_MAX_ATOMS * 4, false);
+         sim->eam_pot.atomRowCount = dalloc<unsigned short>(nBricks * EAM_ATOM_MAX_ATOMS * 2, false);      // (a 32-bit word per atom: the three runs' counts)
          sim->eam_pot.atomBrickSel = dalloc<unsigned long long>((size_t)sim->boxes.nLocalBoxes, false);
          HIP_CHECK(hipMemsetAsync(sim->eam_pot.atomBrickSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(unsigned long long), st));
       }
@@ -1217,12 +1220,14 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: thread_atom needs %zu bytes of LDS for this box\n", lds); exit(-1); }
    const int grid = group ? sim->eam_pot.brickCount[group - 1] : b.geom.g[0] * b.nby * b.nbz;
    if (grid <= 0) return;
+   // threads: the waves that take atoms, and enough to ask for the 16 first slots of every block cell in EAM_BRICK_STAGE rounds
+   const int nThreads = (b.listRounds > 256 || 3 * (b.by + 2) * (b.bz + 2) * 16 > EAM_BRICK_STAGE * 256) ? EAM_ATOM_BRICK_THREADS : 256;
    const double rcut = sim->eam_pot.cutoff * (1.0 + 4e-16);      // (as launchEamBrick: the table clamps are dead weight when every evaluated pair lies inside the tables)
    const bool clampFree = !spline && a.phi.x0 <= R(0.0) && a.rho.x0 <= R(0.0) && rcut <= (double)a.phi.xn && rcut <= (double)a.rho.xn
                           && !(getenv("COMD_EAM_CLAMP") && atoi(getenv("COMD_EAM_CLAMP")) != 0);
 #define COMD_LAUNCH_EAM_ATOM_BRICK(TAB, SPL, CLP) do { \
       allowDynamicLds((const void*)EAM_Force_atom_brick<STEP, TAB, SPL, CLP>, lds); \
-      hipLaunchKernelGGL((EAM_Force_atom_brick<STEP, TAB, SPL, CLP>), dim3(grid), dim3(EAM_ATOM_BRICK_THREADS), lds, st, a, b); } while (0)
+      hipLaunchKernelGGL((EAM_Force_atom_brick<STEP, TAB, SPL, CLP>), dim3(grid), dim3(nThreads), lds, st, a, b); } while (0)
    if (spline)           COMD_LAUNCH_EAM_ATOM_BRICK(false, true, true);
    else if (tablesInLds) { if (clampFree) COMD_LAUNCH_EAM_ATOM_BRICK(true, false, false); else COMD_LAUNCH_EAM_ATOM_BRICK(true, false, true); }
    else                  { if (clampFree) COMD_LAUNCH_EAM_ATOM_BRICK(false, false, false); else COMD_LAUNCH_EAM_ATOM_BRICK(false, false, true); }

@@ -3,7 +3,7 @@
 // Physics and results of the reference's EAM_Force_thread_atom<step> (gpu_eam_thread_atom.h:32-140): one THREAD owns one atom from the first candidate to the
 // stores.  What round 2's kernel of that shape (eam_kernels.h) paid for was the walk: every thread streamed the 283 atoms of its 27-cell stencil from L2 and
 // evaluated under divergence with one lane in seven inside the cutoff.  Here
-//   * a workgroup owns a brick of 1 x BY x BZ link cells (default 1 x 4 x 4) and stages the 3 x (BY + 2) x (BZ + 2) cells around it ONCE into the LDS, densely
+//   * a workgroup owns a brick of 1 x BY x BZ link cells (comd_device.hip picks the shape) and stages the 3 x (BY + 2) x (BZ + 2) cells around it ONCE into the LDS, densely
 //     packed, z-y-x order (the staging of eam_brick_kernels.h: the stencil of a cell is three contiguous runs of records);
 //   * thread t takes the brick's t-th atom and works in two phases.  TEST: walk the three runs of its cell's stencil -- lanes of one cell read the same record
 //     (an LDS broadcast) -- and append the records inside the cutoff to a row of its own in the LDS: one BYTE per neighbour, its offset inside its run (a
@@ -26,7 +26,9 @@
 #pragma once
 #include "eam_brick_kernels.h"
 
-#define EAM_ATOM_BRICK_THREADS 256
+#define EAM_ATOM_BRICK_THREADS 384       // the largest workgroup (six waves); a launch uses 256 or 384 (comd_device.hip: enough for the block's slots in EAM_BRICK_STAGE rounds)
+#define EAM_ATOM_MAX_CELLS 192           // cells of the staged block: 3 * (BY + 2) * (BZ + 2) <= 192 (three per lane of the wave that scans their occupancies)
+#define EAM_ATOM_MAX_ATOMS 512           // atoms of a brick that can leave a row for pass 3
 
 #define EAM_ATOM_ROW_CHUNKS 4            // 16-byte chunks of a row handed from pass 1 to pass 3: rows of up to 64 bytes
 // a thread's row: `rows` bytes + 4 of padding (a group of four candidates is appended before the row's end is looked at; an odd count of dwords for rows % 8 == 0)
@@ -37,18 +39,19 @@ __host__ __device__ static inline int eamAtomBrickRowStride(int rows) { return r
 // (ldsRows: pass 1 always; pass 3 only when it cannot read the rows of pass 1)
 static inline size_t eamAtomBrickLdsBytes(int step, size_t tableDoubles, int imageCap, int rows, int rowThreads, bool ldsRows)
 {
-   return eamTableBytesAligned(tableDoubles) + eamBrickSharedBytes(step, imageCap) + (68 + 64) * sizeof(int)
-          + (ldsRows ? (size_t)rowThreads * eamAtomBrickRowStride(rows) + 16 : 0);
+   return eamTableBytesAligned(tableDoubles) + ((((size_t)(step == 3 ? 4 : 3) * imageCap * sizeof(real_t)) + 15) & ~(size_t)15)      // records (+ F' in pass 3)
+          + (size_t)(EAM_ATOM_MAX_CELLS + 4) * 4 + (size_t)EAM_ATOM_MAX_CELLS * 4 + 64 + 64       // offsets, cell ids, scalars, list of selected cells
+          + (68 + 64) * sizeof(int) + (ldsRows ? (size_t)rowThreads * eamAtomBrickRowStride(rows) + 16 : 0);
 }
 
 template <int STEP, bool LDS_TABLES, bool SPLINE, bool CLAMP>
-__global__ __launch_bounds__(EAM_ATOM_BRICK_THREADS, 3)
+__global__ __launch_bounds__(EAM_ATOM_BRICK_THREADS, 2)
 void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
 {
    static_assert(STEP == 1 || STEP == 3, "passes 1 and 3");
    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
    constexpr int REC = 3, SLOT_BITS = 4, SLOTS = 1 << SLOT_BITS, STAGE = EAM_BRICK_STAGE;
-   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), nThreads = EAM_ATOM_BRICK_THREADS, nWaves = nThreads >> 6;
+   const int tid = threadIdx.x, lane = tid & 63, wave = uniform(tid >> 6), nThreads = blockDim.x, nWaves = nThreads >> 6;
    const int nRhoPad = a.rho.n + 3;
    const bool sameGrid = (STEP == 1) && LDS_TABLES && a.phi.n == a.rho.n && a.phi.x0 == a.rho.x0 && a.phi.invDx == a.rho.invDx;
    real_t* sRho = (real_t*)ldsRaw;
@@ -59,8 +62,8 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    real_t* __restrict__ sp = (real_t*)(ldsRaw + eamTableBytesAligned(tableDoubles));
    real_t* __restrict__ sd = sp + REC * b.imageCap;          // [imageCap] F' (pass 3)
    int* sOff = (int*)(ldsRaw + eamTableBytesAligned(tableDoubles) + ((((size_t)(STEP == 3 ? 4 : 3) * b.imageCap * sizeof(real_t)) + 15) & ~(size_t)15));
-   int* sBox = sOff + EAM_BRICK_MAX_CELLS + 4;               // [128] cell ids of the block
-   int* sMisc = sBox + EAM_BRICK_MAX_CELLS;                  // [16]: 0/1 selection mask, 4 records in the image
+   int* sBox = sOff + EAM_ATOM_MAX_CELLS + 4;                // [192] cell ids of the block
+   int* sMisc = sBox + EAM_ATOM_MAX_CELLS;                   // [16]: 0/1 selection mask, 4 records in the image
    unsigned char* sList = (unsigned char*)(sMisc + 16);      // [64] selected cells of the brick, compacted
    int* sOwn = (int*)(sList + 64);                           // [65] atoms of the selected cells before cell k of that list
    int* sFull = sOwn + 68;                                   // [64] atoms of the brick before brick cell c, selected or not (the hand-over's atom index)
@@ -154,13 +157,14 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          }
          return box;
       };
-      const int boxLo = blockBox(lane), boxHi = blockBox(64 + lane);
-      if (wave < 2) myBox = wave == 0 ? boxLo : boxHi;
+      const int boxLo = blockBox(lane), boxHi = blockBox(64 + lane), boxTop = blockBox(128 + lane);
+      if (wave < 3) myBox = wave == 0 ? boxLo : wave == 1 ? boxHi : boxTop;
 #pragma unroll
       for (int k = 0; k < STAGE; ++k) {
          const int task = k * nThreads + tid, h = task >> SLOT_BITS;
          const int fromLo = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxLo), fromHi = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxHi);
-         request(k, h < NH ? (h < 64 ? fromLo : fromHi) : -1, task & (SLOTS - 1));
+         const int fromTop = __builtin_amdgcn_ds_bpermute((h & 63) << 2, boxTop);
+         request(k, h < NH ? (h < 64 ? fromLo : h < 128 ? fromHi : fromTop) : -1, task & (SLOTS - 1));
       }
    }
    int myCnt = 0;
@@ -174,16 +178,16 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
       }
    }
    const TableView rhoT = makeTable(a.rho, LDS_TABLES ? sRho : a.rho.values), phiT = makeTable(a.phi, LDS_TABLES ? sPhi : a.phi.values);
-   if (tid < EAM_BRICK_MAX_CELLS) { sBox[tid] = myBox >= 0 ? myBox : 0; sOff[tid] = myCnt; }
+   if (tid < EAM_ATOM_MAX_CELLS) { sBox[tid] = myBox >= 0 ? myBox : 0; sOff[tid] = myCnt; }
    __syncthreads();
-   if (wave == 0) {                                          // exclusive scan of the 128 counts: lane l takes entries 2l and 2l + 1
-      const int c0 = sOff[2 * lane], c1 = sOff[2 * lane + 1];
-      int incl = c0 + c1;
+   if (wave == 0) {                                          // exclusive scan of the 192 counts: lane l takes entries 3l, 3l + 1, 3l + 2
+      const int c0 = sOff[3 * lane], c1 = sOff[3 * lane + 1], c2 = sOff[3 * lane + 2];
+      int incl = c0 + c1 + c2;
 #pragma unroll
       for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
-      const int excl = incl - c0 - c1;
-      sOff[2 * lane] = excl; sOff[2 * lane + 1] = excl + c0;
-      if (lane == 63) { sOff[EAM_BRICK_MAX_CELLS] = incl; sMisc[4] = incl; }
+      const int excl = incl - c0 - c1 - c2;
+      sOff[3 * lane] = excl; sOff[3 * lane + 1] = excl + c0; sOff[3 * lane + 2] = excl + c0 + c1;
+      if (lane == 63) { sOff[EAM_ATOM_MAX_CELLS] = incl; sMisc[4] = incl; }
       // the brick's own atoms, cell after cell of the selection: lane k = the k-th selected cell
       __builtin_amdgcn_wave_barrier();
       int own = 0;
@@ -227,18 +231,18 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    uint4 pre[CH];
    unsigned preN = 0xffffffffu;
    unsigned long long preSel = ~selMask;
-   const uint4* __restrict__ rowsG4 = reinterpret_cast<const uint4*>(b.rowsG) + (size_t)bid * CH * 256;      // [brick][chunk][256 atoms]
-   unsigned* __restrict__ rowCountG = reinterpret_cast<unsigned*>(b.rowCountG) + (size_t)bid * 256;        // [brick][256 atoms] n0 | n1 << 8 | n2 << 16
+   const uint4* __restrict__ rowsG4 = reinterpret_cast<const uint4*>(b.rowsG) + (size_t)bid * CH * EAM_ATOM_MAX_ATOMS;      // [brick][chunk][atom of the brick]
+   unsigned* __restrict__ rowCountG = reinterpret_cast<unsigned*>(b.rowCountG) + (size_t)bid * EAM_ATOM_MAX_ATOMS;        // [brick][atom of the brick] n0 | n1 << 8 | n2 << 16
 #pragma unroll
    for (int c = 0; c < CH; ++c) pre[c] = make_uint4(0u, 0u, 0u, 0u);
    if (STEP == 3 && b.rowsG && (wave << 6) < rowThreads && (wave << 6) < nOwn) {
       int cl, ia; ownAtom((wave << 6) + lane < nOwn ? (wave << 6) + lane : nOwn - 1, cl, ia);
       const int full = sFull[cl] + ia;
-      if (full < 256) {
+      if (full < EAM_ATOM_MAX_ATOMS) {
          preN = rowCountG[full];
          preSel = b.brickSel[sBox[1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1))]];
 #pragma unroll
-         for (int c = 0; c < CH; ++c) pre[c] = rowsG4[c * 256 + full];
+         for (int c = 0; c < CH; ++c) pre[c] = rowsG4[c * EAM_ATOM_MAX_ATOMS + full];
       }
    }
    if (STEP == 1 && b.rowsG && wave == 0 && lane < nSel) {
@@ -421,11 +425,11 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          const int S1 = (n0 + 1) & ~1, S2 = S1 + ((n1 + 1) & ~1), total = S2 + n2;
          if (STEP == 1 && b.rowsG && firstRound && have) {      // leave the row for pass 3 (a row that outgrew its capacity: marked, pass 3 walks again)
             const int full = sFull[cl] + ia;
-            if (full < 256) {
+            if (full < EAM_ATOM_MAX_ATOMS) {
                rowCountG[full] = over ? 0xffffffffu : (unsigned)n0 | ((unsigned)n1 << 8) | ((unsigned)n2 << 16);
-               uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + (size_t)bid * CH * 256 + full;
+               uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + (size_t)bid * CH * EAM_ATOM_MAX_ATOMS + full;
                const unsigned* __restrict__ rowR = reinterpret_cast<const unsigned*>(myRow);
-               for (int c = 0; c < (over ? 0 : (total + 15) >> 4); ++c) dst[c * 256] = make_uint4(rowR[4 * c], rowR[4 * c + 1], rowR[4 * c + 2], rowR[4 * c + 3]);
+               for (int c = 0; c < (over ? 0 : (total + 15) >> 4); ++c) dst[c * EAM_ATOM_MAX_ATOMS] = make_uint4(rowR[4 * c], rowR[4 * c + 1], rowR[4 * c + 2], rowR[4 * c + 3]);
             }
          }
          // EVALUATE
