@@ -1140,7 +1140,7 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    int rowsForced = 0;
    { const char* e = getenv("COMD_EAM_ATOM_ROWS"); if (e && atoi(e) >= 8 && atoi(e) <= 128) rows = rowsForced = atoi(e) / 8 * 8; }      // tests: rows that overflow
    EamBrickArgs b;
-   eamBrickGeometry(sim, false, &b);
+   { const int by = sim->eam_pot.brickBy, bz = sim->eam_pot.brickBz; eamBrickGeometry(sim, false, &b); sim->eam_pot.brickBy = by; sim->eam_pot.brickBz = bz; }      // (the grid; the shape is this method's own)
    const double perCell = 4.0 / (lat * lat * lat) / (sim->boxes.invBoxSize[0] * sim->boxes.invBoxSize[1] * sim->boxes.invBoxSize[2]);      // atoms of a cell at the lattice's density
    // the threads that take atoms: whole waves for the brick's atoms + 8 % (a fuller brick's threads take a second atom)
    auto rowThreadsOf = [&](double atoms) { int t = ((int)(atoms * 1.08) + 63) / 64 * 64; return t < 64 ? 64 : t > EAM_ATOM_BRICK_THREADS ? EAM_ATOM_BRICK_THREADS : t; };
