@@ -343,19 +343,21 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
             if (ax * ax + ay * ay + az * az <= a.rc2 && r != recI) evalTrip(r, recI, false);
          }
       };
-      // pass 3: the rows of pass 1, when every atom of the wave has one that was numbered against this image
-      bool handed = false;
-      if (STEP == 3 && firstRound && __builtin_amdgcn_ballot_w64(preN != 0xffffffffu && preSel == selMask) == ~0ull) {
-         handed = true;
-         const int n0 = (int)(preN & 0xffu), n1 = (int)((preN >> 8) & 0xffu), n2 = (int)((preN >> 16) & 0xffu);
-         const int S1 = (n0 + 1) & ~1, S2 = S1 + ((n1 + 1) & ~1), total = (b.debug & 2) ? 0 : S2 + n2;
-         const unsigned wr[4 * CH] = { pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w,
-                                       pre[2].x, pre[2].y, pre[2].z, pre[2].w, pre[3].x, pre[3].y, pre[3].z, pre[3].w };
+      // pass 3: the row of pass 1, when the atom has one that was numbered against this image.  Without rows in the LDS (the launcher found rows to read) the lanes
+      // choose for themselves: an atom without a valid row -- its brick staged under another selection, its row overflowed, a second-round atom -- walks its stencil
+      // again while the others evaluate from their registers; with rows in the LDS a wave in which any atom has none takes the TEST phase as pass 1 does.
+      const bool rowValid = STEP == 3 && firstRound && preN != 0xffffffffu && preSel == selMask;
+      const bool handed = STEP == 3 && (ldsRows ? __builtin_amdgcn_ballot_w64(rowValid) == ~0ull : true);
+      if (handed) {
+         if (rowValid) {
+            const int n0 = (int)(preN & 0xffu), n1 = (int)((preN >> 8) & 0xffu), n2 = (int)((preN >> 16) & 0xffu);
+            const int S1 = (n0 + 1) & ~1, S2 = S1 + ((n1 + 1) & ~1), total = (b.debug & 2) ? 0 : S2 + n2;
+            const unsigned wr[4 * CH] = { pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, pre[1].z, pre[1].w,
+                                          pre[2].x, pre[2].y, pre[2].z, pre[2].w, pre[3].x, pre[3].y, pre[3].z, pre[3].w };
 #pragma unroll
-         for (int tr = 0; tr < 8 * CH; ++tr)               // (unrolled: the words sit in registers; a trip no lane has is a skipped branch)
-            if (2 * tr < total) tripOf(2 * tr, (tr & 1) ? wr[tr >> 1] >> 16 : wr[tr >> 1], S1, S2, n0, S1 + n1, total);
-      } else if (STEP == 3 && !ldsRows) {
-         directWalk();
+            for (int tr = 0; tr < 8 * CH; ++tr)            // (unrolled: the words sit in registers; a trip no lane has is a skipped branch)
+               if (2 * tr < total) tripOf(2 * tr, (tr & 1) ? wr[tr >> 1] >> 16 : wr[tr >> 1], S1, S2, n0, S1 + n1, total);
+         } else directWalk();
       } else {
          // TEST.  Four candidates per group, the records of the NEXT group requested before the current one is tested (two register sets, ping-pong): the walk
          // lives on LDS latency, and a brick workgroup's waves are few.  The groups every lane of the wave has whole are walked without masks, addresses as

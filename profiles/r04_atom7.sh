@@ -1,6 +1,6 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p $R/gpurun_out
-bash $R/profiles/r04_sweep.sh "--pot eam --method thread_atom --steps 20 --warmup 5" COMD_EAM_ATOM_BRICK 4,4 5,6 5,5 4,6 6,5 4,5
+bash $R/profiles/r04_sweep.sh "--pot eam --method thread_atom --steps 20 --warmup 5" COMD_EAM_ATOM_ROWS 0 48
 python3 -m pytest $R/tests -m gpu -x -q -k "thread_atom_on_the_brick or hand_over or (thread_atom and (eam or any_cell or recorded or sweep))" > $R/gpurun_out/r04_atom_tests.log 2>&1 || { tail -40 $R/gpurun_out/r04_atom_tests.log; exit 1; }
 tail -2 $R/gpurun_out/r04_atom_tests.log
