@@ -557,7 +557,7 @@ def test_halo_cells_are_periodic_images(gpu):
 
 
 # ---------------------------------------------------------------- properties at BASELINE size
-@pytest.mark.parametrize("eam,method,steps", [(0, "thread_atom", 10), (1, "cta_cell", 20)])
+@pytest.mark.parametrize("eam,method,steps", [(0, "thread_atom", 10), (1, "cta_cell", 20), (1, "thread_atom", 20)])
 def test_full_size_properties(gpu, eam, method, steps):
     """80^3 (2,048,000 atoms), BASELINE configs 2 and 3: the oracle is too slow here, so check what the physics guarantees:
     step-0 energy equals the recorded reference value, total energy is conserved, total momentum stays zero,
