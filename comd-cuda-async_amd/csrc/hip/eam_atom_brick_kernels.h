@@ -123,7 +123,7 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    const bool plain = !b.geom.lookup && selMask == (NC >= 64 ? ~0ull : (1ull << NC) - 1ull) && bx >= 1 && bx <= gx - 2 && by0 >= 1 && by0 + b.by <= gy - 1
                       && bz0 >= 1 && bz0 + b.bz <= gz - 1;
    if (plain) {
-      const int hyMagic = (65536 + HY - 1) / HY;             // t / HY = (t * hyMagic) >> 16 for t < 128
+      const int hyMagic = (65536 + HY - 1) / HY;             // t / HY = (t * hyMagic) >> 16 for t < 128 (t = h / 3 < 64)
       const int base = (bx - 1) + gx * ((by0 - 1) + gy * (bz0 - 1)), gxy = gx * gy;
       auto plainBox = [&](const int h) {                     // h = xh + 3 (yh + HY zh)
          const int t = (h * 171) >> 9, xh = h - 3 * t, zh = (t * hyMagic) >> 16, yh = t - zh * HY;
@@ -136,7 +136,7 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          request(k, h < NH ? plainBox(h) : -1, task & (SLOTS - 1));
       }
    } else {
-      // every wave works out the cell ids of all 128 block cells (two per lane; -1: outside the grid or in no selected cell's stencil -- a launch over the
+      // every wave works out the cell ids of all 192 block cells (three per lane; -1: outside the grid or in no selected cell's stencil -- a launch over the
       // interior cells runs while the halo cells are being filled and must not look at them)
       auto blockBox = [&](const int h) {
          int box = -1;
