@@ -44,6 +44,31 @@ static inline size_t eamAtomBrickLdsBytes(int step, size_t tableDoubles, int ima
           + (68 + 64) * sizeof(int) + (ldsRows ? (size_t)rowThreads * eamAtomBrickRowStride(rows) + 16 : 0);
 }
 
+// Scans and reductions over the 64 lanes on the DPP path (row shifts inside the rows of 16, then the row ends broadcast: six VALU instructions) -- as
+// __shfl_up loops they are six ds_bpermute round trips through the LDS each, and the TEST phase wants a wave minimum per run.  Every lane must be active.
+__device__ __forceinline__ int waveInclusiveScan(int v)
+{
+   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);       // row_shr:1 (a lane without a source adds 0)
+   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);       // row_shr:2
+   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);       // row_shr:4
+   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);       // row_shr:8: inclusive inside each row of 16
+   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+   return v;
+}
+__device__ __forceinline__ int waveMin(int v)
+{
+   constexpr int BIG = 0x7fffffff;
+   int o;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x111, 0xf, 0xf, false); v = o < v ? o : v;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x112, 0xf, 0xf, false); v = o < v ? o : v;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x114, 0xf, 0xf, false); v = o < v ? o : v;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x118, 0xf, 0xf, false); v = o < v ? o : v;      // lane 15 of a row: the row's minimum
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x142, 0xa, 0xf, false); v = o < v ? o : v;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x143, 0xc, 0xf, false); v = o < v ? o : v;
+   return __builtin_amdgcn_readlane(v, 63);
+}
+
 template <int STEP, bool LDS_TABLES, bool SPLINE, bool CLAMP>
 __global__ __launch_bounds__(EAM_ATOM_BRICK_THREADS, 2)
 void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
@@ -182,9 +207,7 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    __syncthreads();
    if (wave == 0) {                                          // exclusive scan of the 192 counts: lane l takes entries 3l, 3l + 1, 3l + 2
       const int c0 = sOff[3 * lane], c1 = sOff[3 * lane + 1], c2 = sOff[3 * lane + 2];
-      int incl = c0 + c1 + c2;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+      const int incl = waveInclusiveScan(c0 + c1 + c2);
       const int excl = incl - c0 - c1 - c2;
       sOff[3 * lane] = excl; sOff[3 * lane + 1] = excl + c0; sOff[3 * lane + 2] = excl + c0 + c1;
       if (lane == 63) { sOff[EAM_ATOM_MAX_CELLS] = incl; sMisc[4] = incl; }
@@ -195,15 +218,10 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          const int cl = sList[lane], hc = 1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1));
          own = sOff[hc + 1] - sOff[hc];
       }
-      int inclOwn = own;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inclOwn, d); if (lane >= d) inclOwn += up; }
+      const int inclOwn = waveInclusiveScan(own);
       sOwn[lane + 1] = inclOwn;
       if (lane == 0) sOwn[0] = 0;
-      int inclFull = brickCnt;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(inclFull, d); if (lane >= d) inclFull += up; }
-      sFull[lane] = inclFull - brickCnt;
+      sFull[lane] = waveInclusiveScan(brickCnt) - brickCnt;
    }
    __syncthreads();
    const int imageTotal = uniform(sMisc[4]);
@@ -374,10 +392,7 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
             const int rs = p == 0 ? rs0 : p == 1 ? rs1 : rs2, len = (b.debug & 1) ? 0 : p == 0 ? len0 : p == 1 ? len1 : len2;
             unsigned char* const wStart = w;
             real_t ax[G], ay[G], az[G], cx[G], cy[G], cz[G];
-            int whole = len / (2 * G);
-#pragma unroll
-            for (int m = 32; m >= 1; m >>= 1) { const int o = __shfl_xor(whole, m); whole = o < whole ? o : whole; }
-            whole = uniform(whole);
+            const int whole = waveMin(len / (2 * G));
             int u = 0;
             if (whole > 0) {
                const real_t* __restrict__ q = sp + REC * rs;
