@@ -44,31 +44,7 @@ static inline size_t eamAtomBrickLdsBytes(int step, size_t tableDoubles, int ima
           + (68 + 64) * sizeof(int) + (ldsRows ? (size_t)rowThreads * eamAtomBrickRowStride(rows) + 16 : 0);
 }
 
-// Scans and reductions over the 64 lanes on the DPP path (row shifts inside the rows of 16, then the row ends broadcast: six VALU instructions) -- as
-// __shfl_up loops they are six ds_bpermute round trips through the LDS each, and the TEST phase wants a wave minimum per run.  Every lane must be active.
-__device__ __forceinline__ int waveInclusiveScan(int v)
-{
-   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);       // row_shr:1 (a lane without a source adds 0)
-   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);       // row_shr:2
-   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);       // row_shr:4
-   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);       // row_shr:8: inclusive inside each row of 16
-   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
-   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
-   return v;
-}
-__device__ __forceinline__ int waveMin(int v)
-{
-   constexpr int BIG = 0x7fffffff;
-   int o;
-   o = __builtin_amdgcn_update_dpp(BIG, v, 0x111, 0xf, 0xf, false); v = o < v ? o : v;
-   o = __builtin_amdgcn_update_dpp(BIG, v, 0x112, 0xf, 0xf, false); v = o < v ? o : v;
-   o = __builtin_amdgcn_update_dpp(BIG, v, 0x114, 0xf, 0xf, false); v = o < v ? o : v;
-   o = __builtin_amdgcn_update_dpp(BIG, v, 0x118, 0xf, 0xf, false); v = o < v ? o : v;      // lane 15 of a row: the row's minimum
-   o = __builtin_amdgcn_update_dpp(BIG, v, 0x142, 0xa, 0xf, false); v = o < v ? o : v;
-   o = __builtin_amdgcn_update_dpp(BIG, v, 0x143, 0xc, 0xf, false); v = o < v ? o : v;
-   return __builtin_amdgcn_readlane(v, 63);
-}
-
+// (the scans and the per-run wave minimum run on the DPP path: waveInclusiveScan, waveMin of eam_brick_kernels.h)
 template <int STEP, bool LDS_TABLES, bool SPLINE, bool CLAMP>
 __global__ __launch_bounds__(EAM_ATOM_BRICK_THREADS, 2)
 void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)

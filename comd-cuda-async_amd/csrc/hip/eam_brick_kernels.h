@@ -37,6 +37,31 @@
 #define EAM_BRICK_STAGE_LISTED 10         // listed launches stage 32 slots per cell (cells of cutoff + skin hold 14 atoms on average): 256 x 10 = 80 cells x 32 slots
 #define EAM_LIST_WORDS 12                 // words (two 16-bit numbers each) a lane holds of a listed row: 3 quads
 
+// Scans and reductions over the 64 lanes on the DPP path (row shifts inside the rows of 16, then the row ends broadcast: six VALU instructions) -- as
+// __shfl_up loops they are six ds_bpermute round trips through the LDS each.  Every lane must be active.
+__device__ __forceinline__ int waveInclusiveScan(int v)
+{
+   v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);       // row_shr:1 (a lane without a source adds 0)
+   v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);       // row_shr:2
+   v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);       // row_shr:4
+   v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);       // row_shr:8: inclusive inside each row of 16
+   v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1 and 3
+   v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2 and 3
+   return v;
+}
+__device__ __forceinline__ int waveMin(int v)
+{
+   constexpr int BIG = 0x7fffffff;
+   int o;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x111, 0xf, 0xf, false); v = o < v ? o : v;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x112, 0xf, 0xf, false); v = o < v ? o : v;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x114, 0xf, 0xf, false); v = o < v ? o : v;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x118, 0xf, 0xf, false); v = o < v ? o : v;      // lane 15 of a row: the row's minimum
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x142, 0xa, 0xf, false); v = o < v ? o : v;
+   o = __builtin_amdgcn_update_dpp(BIG, v, 0x143, 0xc, 0xf, false); v = o < v ? o : v;
+   return __builtin_amdgcn_readlane(v, 63);
+}
+
 struct EamBrickArgs {
    CellGeom geom;                         // local grid (+ -H lookup tables, device pointers)
    int by, bz;                            // brick extent in y and z (cells); x extent is 1
@@ -253,9 +278,7 @@ void EAM_Force_cta_brick(EamArgs a, EamBrickArgs b)
    __syncthreads();
    if (wave == 0) {                                          // exclusive scan of the 128 counts: lane l takes entries 2l and 2l + 1
       const int c0 = sOff[2 * lane], c1 = sOff[2 * lane + 1];
-      int incl = c0 + c1;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d); if (lane >= d) incl += up; }
+      const int incl = waveInclusiveScan(c0 + c1);
       const int excl = incl - c0 - c1;
       sOff[2 * lane] = excl; sOff[2 * lane + 1] = excl + c0;
       if (lane == 63) { sOff[EAM_BRICK_MAX_CELLS] = incl; sMisc[4] = incl; }
