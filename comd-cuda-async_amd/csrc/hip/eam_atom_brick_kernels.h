@@ -360,7 +360,8 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          // looked at once per group (the row's padding takes the group).  Only the middle plane holds the atom itself.
          unsigned char* w = myRow;
          unsigned char* const wEnd = myRow + b.rows;
-         bool over = len0 > 256 || len1 > 256 || len2 > 256;      // an offset would not fit a byte: no row
+         const int runMax = (b.debug & 16) ? 64 : 256;           // (COMD_EAM_ABLATE=16, tests: the walk without a row for every atom of a normal lattice)
+         bool over = len0 > runMax || len1 > runMax || len2 > runMax;      // an offset would not fit a byte: no row
          int cnt[3] = { 0, 0, 0 };
          constexpr int G = 4;
 #pragma unroll

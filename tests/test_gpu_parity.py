@@ -167,12 +167,13 @@ def test_eam_overlap_mode_takes_whole_bricks(gpu, orc, monkeypatch, env):
 
 @pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("env", [{}, {"COMD_EAM_ATOM_HANDOVER": "0"}, {"COMD_EAM_IMAGE": "128"}, {"COMD_EAM_IMAGE": "1500"}, {"COMD_EAM_ATOM_BRICK": "2,3"},
-                                 {"COMD_EAM_ATOM_BRICK": "4,5"}, {"COMD_EAM_ATOM_ROWS": "16"}, {"COMD_EAM_ATOM_ROWS": "48"}, {"COMD_EAM_THREAD_ATOM": "cell"}, {"COMD_EAM_GROUPS": "0"}])
+                                 {"COMD_EAM_ATOM_BRICK": "4,5"}, {"COMD_EAM_ATOM_ROWS": "16"}, {"COMD_EAM_ATOM_ROWS": "48"}, {"COMD_EAM_THREAD_ATOM": "cell"}, {"COMD_EAM_GROUPS": "0"}, {"COMD_EAM_ABLATE": "16"}])
 def test_eam_thread_atom_on_the_brick_image(gpu, orc, monkeypatch, env, overlap):
     """-m thread_atom -e: a thread per atom inside a brick workgroup (eam_atom_brick_kernels.h).  Legs: the default; pass 3 testing again instead of reading
     the rows of pass 1; an image every brick (128 records) or part of the bricks (1500) outgrow -- those take the streaming form, in both passes; brick shapes
     that do not divide the grid / fill all four waves; rows shorter than the neighbour count of every atom (16: each walks its stencil a second time) or of
-    some atoms (48); round 2's kernel; the lists of -a 1 taken cell by cell (COMD_EAM_GROUPS=0: bricks that hold cells of both lists are staged under two
+    some atoms (48); stencil runs too long for byte offsets (COMD_EAM_ABLATE=16 lowers the limit from 256 records to 64: every atom walks without a row, in both
+    passes); round 2's kernel; the lists of -a 1 taken cell by cell (COMD_EAM_GROUPS=0: bricks that hold cells of both lists are staged under two
     selections, the hand-over must notice) instead of as whole bricks.  Each without and with -a 1 (every pass once over the boundary and once over the
     interior cells).  Forces, energies, densities, dF/drho against the oracle."""
     for k, v in env.items():
