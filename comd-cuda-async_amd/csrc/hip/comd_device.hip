@@ -1189,11 +1189,12 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
    b.fuseEmbed = sim->fuseEmbed; b.status = sim->status;
    { const char* e = getenv("COMD_EAM_ABLATE"); b.debug = e ? atoi(e) : 0; }
    // the rows pass 1 leaves for pass 3 (eam_atom_brick_kernels.h; COMD_EAM_ATOM_HANDOVER=0: pass 3 tests again, A/B runs)
+   const int rowCap = b.listRounds <= 192 ? 256 : 512;      // atoms of a brick that can leave a row (a brick fuller than that: its last atoms walk again in pass 3)
    if (handOver && rows <= 16 * EAM_ATOM_ROW_CHUNKS) {
       const size_t nBricks = (size_t)b.geom.g[0] * b.nby * b.nbz;
       if (!sim->eam_pot.atomRows) {
-         sim->eam_pot.atomRows = dalloc<unsigned>(nBricks * EAM_ATOM_ROW_CHUNKS * EAM_ATOM_MAX_ATOMS * 4, false);
-         sim->eam_pot.atomRowCount = dalloc<unsigned short>(nBricks * EAM_ATOM_MAX_ATOMS * 2, false);      // (a 32-bit word per atom: the three runs' counts)
+         sim->eam_pot.atomRows = dalloc<unsigned>(nBricks * EAM_ATOM_ROW_CHUNKS * rowCap * 4, false);
+         sim->eam_pot.atomRowCount = dalloc<unsigned short>(nBricks * rowCap * 2, false);      // (a 32-bit word per atom: the three runs' counts)
          sim->eam_pot.atomBrickSel = dalloc<unsigned long long>((size_t)sim->boxes.nLocalBoxes, false);
          HIP_CHECK(hipMemsetAsync(sim->eam_pot.atomBrickSel, 0, (size_t)sim->boxes.nLocalBoxes * sizeof(unsigned long long), st));
       }
@@ -1214,8 +1215,8 @@ static void launchEamAtomBrick(SimGpu* sim, const EamArgs& a, int num_cells, int
       hipLaunchKernelGGL(MarkCells, dim3(ceilDiv(num_cells, 256)), dim3(256), 0, st, cells_list, num_cells, sim->eam_pot.cellSel, b.tag);
    }
    // pass 3 keeps rows in the LDS only when it has none to read: what they would take is the third workgroup of a CU
-   b.listQuads = (STEP == 3 && b.rowsG) ? 0 : 1;
-   size_t lds = eamAtomBrickLdsBytes(STEP, tableDoublesOf(STEP), b.imageCap, b.rows, b.listRounds, b.listQuads != 0);
+   b.listQuads = ((STEP == 3 && b.rowsG) ? 0 : 1) | (rowCap << 8);
+   size_t lds = eamAtomBrickLdsBytes(STEP, tableDoublesOf(STEP), b.imageCap, b.rows, b.listRounds, (b.listQuads & 1) != 0);
    { const char* e = getenv("COMD_EAM_ATOM_LDS_PAD"); if (e) lds += (size_t)atoi(e); }      // experiments: fewer workgroups per CU
    if (lds > 160 * 1024) { fprintf(stderr, "eamForce: thread_atom needs %zu bytes of LDS for this box\n", lds); exit(-1); }
    const int grid = group ? sim->eam_pot.brickCount[group - 1] : b.geom.g[0] * b.nby * b.nbz;

@@ -28,7 +28,6 @@
 
 #define EAM_ATOM_BRICK_THREADS 384       // the largest workgroup (six waves); a launch uses 256 or 384 (comd_device.hip: enough for the block's slots in EAM_BRICK_STAGE rounds)
 #define EAM_ATOM_MAX_CELLS 192           // cells of the staged block: 3 * (BY + 2) * (BZ + 2) <= 192 (three per lane of the wave that scans their occupancies)
-#define EAM_ATOM_MAX_ATOMS 512           // atoms of a brick that can leave a row for pass 3
 
 #define EAM_ATOM_ROW_CHUNKS 4            // 16-byte chunks of a row handed from pass 1 to pass 3: rows of up to 64 bytes
 // a thread's row: `rows` bytes + 4 of padding (a group of four candidates is appended before the row's end is looked at; an odd count of dwords for rows % 8 == 0)
@@ -214,7 +213,8 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    // own atom t of the brick -> its cell (k-th selected, brick cell cl) and its number in the cell
    const int nOwn = uniform(sOwn[nSel]);
    const int rowThreads = b.listRounds;                      // threads that take atoms (whole waves)
-   const bool ldsRows = STEP == 1 || b.listQuads != 0;       // pass 3 has rows in the LDS only where the launcher found no hand-over to read (else the LDS they would take buys a workgroup per CU)
+   const int rowCap = b.listQuads >> 8;                      // atoms of a brick that can leave a row for pass 3 (the launcher: the row threads rounded up to 256 or 512)
+   const bool ldsRows = STEP == 1 || (b.listQuads & 1) != 0;       // pass 3 has rows in the LDS only where the launcher found no hand-over to read (else the LDS they would take buys a workgroup per CU)
    auto ownAtom = [&](const int t, int& cl, int& ia) {
       int k = 0;
       for (int s = 1; s < nSel; ++s) k += t >= sOwn[s] ? 1 : 0;
@@ -225,18 +225,18 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
    uint4 pre[CH];
    unsigned preN = 0xffffffffu;
    unsigned long long preSel = ~selMask;
-   const uint4* __restrict__ rowsG4 = reinterpret_cast<const uint4*>(b.rowsG) + (size_t)bid * CH * EAM_ATOM_MAX_ATOMS;      // [brick][chunk][atom of the brick]
-   unsigned* __restrict__ rowCountG = reinterpret_cast<unsigned*>(b.rowCountG) + (size_t)bid * EAM_ATOM_MAX_ATOMS;        // [brick][atom of the brick] n0 | n1 << 8 | n2 << 16
+   const uint4* __restrict__ rowsG4 = reinterpret_cast<const uint4*>(b.rowsG) + (size_t)bid * CH * rowCap;      // [brick][chunk][atom of the brick]
+   unsigned* __restrict__ rowCountG = reinterpret_cast<unsigned*>(b.rowCountG) + (size_t)bid * rowCap;        // [brick][atom of the brick] n0 | n1 << 8 | n2 << 16
 #pragma unroll
    for (int c = 0; c < CH; ++c) pre[c] = make_uint4(0u, 0u, 0u, 0u);
    if (STEP == 3 && b.rowsG && (wave << 6) < rowThreads && (wave << 6) < nOwn) {
       int cl, ia; ownAtom((wave << 6) + lane < nOwn ? (wave << 6) + lane : nOwn - 1, cl, ia);
       const int full = sFull[cl] + ia;
-      if (full < EAM_ATOM_MAX_ATOMS) {
+      if (full < rowCap) {
          preN = rowCountG[full];
          preSel = b.brickSel[sBox[1 + 3 * ((cl % b.by + 1) + HY * (cl / b.by + 1))]];
 #pragma unroll
-         for (int c = 0; c < CH; ++c) pre[c] = rowsG4[c * EAM_ATOM_MAX_ATOMS + full];
+         for (int c = 0; c < CH; ++c) pre[c] = rowsG4[c * rowCap + full];
       }
    }
    if (STEP == 1 && b.rowsG && wave == 0 && lane < nSel) {
@@ -419,11 +419,11 @@ void EAM_Force_atom_brick(EamArgs a, EamBrickArgs b)
          const int S1 = (n0 + 1) & ~1, S2 = S1 + ((n1 + 1) & ~1), total = S2 + n2;
          if (STEP == 1 && b.rowsG && firstRound && have) {      // leave the row for pass 3 (a row that outgrew its capacity: marked, pass 3 walks again)
             const int full = sFull[cl] + ia;
-            if (full < EAM_ATOM_MAX_ATOMS) {
+            if (full < rowCap) {
                rowCountG[full] = over ? 0xffffffffu : (unsigned)n0 | ((unsigned)n1 << 8) | ((unsigned)n2 << 16);
-               uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + (size_t)bid * CH * EAM_ATOM_MAX_ATOMS + full;
+               uint4* __restrict__ dst = reinterpret_cast<uint4*>(b.rowsG) + (size_t)bid * CH * rowCap + full;
                const unsigned* __restrict__ rowR = reinterpret_cast<const unsigned*>(myRow);
-               for (int c = 0; c < (over ? 0 : (total + 15) >> 4); ++c) dst[c * EAM_ATOM_MAX_ATOMS] = make_uint4(rowR[4 * c], rowR[4 * c + 1], rowR[4 * c + 2], rowR[4 * c + 3]);
+               for (int c = 0; c < (over ? 0 : (total + 15) >> 4); ++c) dst[c * rowCap] = make_uint4(rowR[4 * c], rowR[4 * c + 1], rowR[4 * c + 2], rowR[4 * c + 3]);
             }
          }
          // EVALUATE
