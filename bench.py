@@ -395,6 +395,8 @@ def main():
             if (pot, meth) in (("eam", "cta_cell"), ("lj", "thread_atom")):      # BASELINE.json configs[2] / configs[1]: a roofline object of their own
                 entry["baseline_config"] = "configs[2]" if pot == "eam" else "configs[1]"
                 entry["roofline"] = roofline_object(pot, meth, a.nx, v["n_global"], v["force_ms"] / a.steps, v["aux_ms"] / a.steps, a.precision)
+            elif (pot, meth) == ("eam", "thread_atom"):      # the second EAM kernel shape north_star names: its roofline object too
+                entry["roofline"] = roofline_object(pot, meth, a.nx, v["n_global"], v["force_ms"] / a.steps, v["aux_ms"] / a.steps, a.precision)
             variants.append(entry)
     # the single-precision build on the two BASELINE workloads: a child process each (the two builds export the same symbols)
     if a.gpus == 1 and not a.no_variants and a.precision == "double":
